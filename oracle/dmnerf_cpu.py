@@ -1,0 +1,314 @@
+"""CPU oracle for the DM-NeRF volumetric-render hot path.
+
+TEST INFRASTRUCTURE ONLY.  This module is a CPU restatement (PyTorch CPU ops, fp32) of
+the reference algorithm.  It is imported only by ``tests/``, ``__graft_entry__.smoke()``
+and the ``cpu_baseline`` leg of ``bench.py`` as the *checker*; the product package
+``dm_nerf_amd`` never imports it and has no CPU fallback.
+
+Parity pin: every function here is checked in ``tests/test_oracle.py`` against golden
+vectors produced by importing the reference itself (``tests/golden/make_golden.py``,
+run in the build container where ``/root/reference`` is mounted; the vectors are
+committed under ``tests/golden/*.npz``).  The reference ships no tests or fixtures of
+its own.
+
+Each function cites the reference lines it restates (paths relative to the reference
+root).  The op *sequence* follows the reference (per-layer ``addmm``, ``cat``-based
+encoding, ``cumprod`` transmittance, ``searchsorted`` sampler) so that timing this
+module is a fair stand-in for the reference's PyTorch-CPU path.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Params = Dict[str, torch.Tensor]
+
+NET_DEPTH = 8          # config.py:23
+NET_WIDTH = 256        # config.py:25
+SKIP_AFTER = 4         # config.py:153,157 -> skips=[4]
+POS_FREQS = 10         # config.py:56
+DIR_FREQS = 4          # config.py:58
+POS_CH = 3 + 6 * POS_FREQS   # 63
+DIR_CH = 3 + 6 * DIR_FREQS   # 27
+
+
+# --------------------------------------------------------------------------------------
+# parameters
+# --------------------------------------------------------------------------------------
+def param_specs(ins_num: int, width: int = NET_WIDTH, depth: int = NET_DEPTH) -> List[Tuple[str, Tuple[int, ...]]]:
+    """Names and shapes of one field network, in the reference's ``state_dict`` order.
+
+    Follows the registration order of ``DM_NeRF.__init__`` (networks/dm_nerf.py:59-78).
+    """
+    specs: List[Tuple[str, Tuple[int, ...]]] = []
+    for i in range(depth):
+        fan_in = POS_CH if i == 0 else (width + POS_CH if i == SKIP_AFTER + 1 else width)
+        specs.append((f"mlps.{i}.weight", (width, fan_in)))
+        specs.append((f"mlps.{i}.bias", (width,)))
+    specs += [
+        ("rgb_feature_linear.weight", (width, width)),
+        ("rgb_feature_linear.bias", (width,)),
+        ("ins_feature_linear.weight", (width, width)),
+        ("ins_feature_linear.bias", (width,)),
+        ("rgb_feature_linears.0.weight", (width // 2, width + DIR_CH)),
+        ("rgb_feature_linears.0.bias", (width // 2,)),
+        ("ins_feature_linears.0.weight", (width // 2, width)),
+        ("ins_feature_linears.0.bias", (width // 2,)),
+        ("density_linear.weight", (1, width)),
+        ("density_linear.bias", (1,)),
+        ("ins_linear.weight", (ins_num + 1, width // 2)),
+        ("ins_linear.bias", (ins_num + 1,)),
+        ("rgb_linear.weight", (3, width // 2)),
+        ("rgb_linear.bias", (3,)),
+    ]
+    return specs
+
+
+def make_params(ins_num: int, seed: int, sharpen: bool = True) -> Params:
+    """Deterministic synthetic weights: PCG64(seed), U(+-1/sqrt(fan_in)) for weight and bias
+    (the distribution of ``nn.Linear``'s default init).  ``sharpen`` scales the
+    density head so that random fields contain opaque structure."""
+    rng = np.random.default_rng(seed)
+    out: Params = {}
+    fan_in = 1
+    for name, shape in param_specs(ins_num):
+        if name.endswith(".weight"):
+            fan_in = shape[1]
+        bound = 1.0 / math.sqrt(fan_in)
+        out[name] = torch.from_numpy(rng.uniform(-bound, bound, size=shape).astype(np.float32))
+    if sharpen:
+        out["density_linear.weight"] = out["density_linear.weight"] * 30.0
+        out["density_linear.bias"] = out["density_linear.bias"] + 0.5
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# rays and depths
+# --------------------------------------------------------------------------------------
+def rays_from_camera(H: int, W: int, K, c2w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Per-pixel ray origins and (un-normalised) directions, ``[H, W, 3]`` each.
+
+    Restates ``get_rays_k`` (networks/helpers.py:50-61): pixel centres at integer
+    coordinates, camera-frame direction ``((w-K02)/K00, (h-K12)/K11, K22)``, rotated by
+    ``c2w[:3,:3]``; origin ``c2w[:3,-1]`` broadcast.
+    """
+    K = np.asarray(K)
+    cols = torch.arange(W, dtype=torch.float32).view(1, W).expand(H, W)
+    rows = torch.arange(H, dtype=torch.float32).view(H, 1).expand(H, W)
+    cam = torch.stack([(cols - K[0, 2]) / K[0, 0],
+                       (rows - K[1, 2]) / K[1, 1],
+                       K[2, 2] * torch.ones_like(cols)], dim=-1)
+    rot = c2w[:3, :3]
+    rays_d = (cam.unsqueeze(-2) * rot).sum(-1)
+    rays_o = c2w[:3, -1].expand(rays_d.shape)
+    return rays_o, rays_d
+
+
+def coarse_depths(n_rays: int, near: float, far: float, n_samples: int) -> torch.Tensor:
+    """``z = near + linspace(0,1,n)*(far-near)`` expanded to ``[n_rays, n]``
+    (``z_val_sample``, networks/helpers.py:114-119)."""
+    lo = near * torch.ones(n_rays, 1)
+    hi = far * torch.ones(n_rays, 1)
+    t = torch.linspace(0.0, 1.0, steps=n_samples)
+    return (lo + t * (hi - lo)).expand(n_rays, n_samples)
+
+
+def jitter_depths(z: torch.Tensor, t_rand: torch.Tensor) -> torch.Tensor:
+    """Stratified jitter inside the coarse bins (networks/render.py:40-47)."""
+    mid = 0.5 * (z[..., 1:] + z[..., :-1])
+    upper = torch.cat([mid, z[..., -1:]], -1)
+    lower = torch.cat([z[..., :1], mid], -1)
+    return lower + (upper - lower) * t_rand
+
+
+# --------------------------------------------------------------------------------------
+# field
+# --------------------------------------------------------------------------------------
+def encode(x: torch.Tensor, n_freqs: int) -> torch.Tensor:
+    """``[x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)]``
+    (``Embedder.embed``, networks/dm_nerf.py:13-38; log-sampled bands ``:25``)."""
+    bands = 2.0 ** torch.linspace(0.0, n_freqs - 1, steps=n_freqs)
+    parts = [x]
+    for f in bands:
+        parts.append(torch.sin(x * f))
+        parts.append(torch.cos(x * f))
+    return torch.cat(parts, -1)
+
+
+def field(params: Params, embedded: torch.Tensor) -> torch.Tensor:
+    """Field network ``[M, 63+27] -> [M, 3+1+ins_num+1]`` (``DM_NeRF.forward``,
+    networks/dm_nerf.py:80-106).  Raw outputs, no activations on the heads."""
+    pos, view = embedded[..., :POS_CH], embedded[..., POS_CH:POS_CH + DIR_CH]
+    h = pos
+    for i in range(NET_DEPTH):
+        h = F.relu(F.linear(h, params[f"mlps.{i}.weight"], params[f"mlps.{i}.bias"]))
+        if i == SKIP_AFTER:
+            h = torch.cat([h, pos], -1)                                   # dm_nerf.py:86-87
+    feat = F.linear(h, params["rgb_feature_linear.weight"], params["rgb_feature_linear.bias"])
+    feat = torch.cat([feat, view], -1)                                    # dm_nerf.py:90
+    feat = F.relu(F.linear(feat, params["rgb_feature_linears.0.weight"], params["rgb_feature_linears.0.bias"]))
+    code = F.linear(h.detach(), params["ins_feature_linear.weight"], params["ins_feature_linear.bias"])  # :95-96
+    code = F.relu(F.linear(code, params["ins_feature_linears.0.weight"], params["ins_feature_linears.0.bias"]))
+    sigma = F.linear(h, params["density_linear.weight"], params["density_linear.bias"])
+    rgb = F.linear(feat, params["rgb_linear.weight"], params["rgb_linear.bias"])
+    ins = F.linear(code, params["ins_linear.weight"], params["ins_linear.bias"])
+    return torch.cat([rgb, sigma, ins], -1)
+
+
+def field_on_rays(params: Params, rays_o: torch.Tensor, rays_d: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+    """Points ``o + d*z`` -> encodings -> field, ``[N, S, C]`` (networks/render.py:37-38,49-61)."""
+    view = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
+    pts = rays_o[..., None, :] + rays_d[..., None, :] * z[..., :, None]
+    flat = pts.reshape(-1, 3)
+    emb = torch.cat([encode(flat, POS_FREQS),
+                     encode(view[:, None].expand(pts.shape).reshape(-1, 3), DIR_FREQS)], -1)
+    raw = field(params, emb)
+    return raw.reshape(*pts.shape[:-1], raw.shape[-1])
+
+
+# --------------------------------------------------------------------------------------
+# compositing and resampling
+# --------------------------------------------------------------------------------------
+def composite(raw: torch.Tensor, z: torch.Tensor, rays_d: torch.Tensor, manipulator: bool = False):
+    """Alpha compositing.  Returns ``(rgb[N,3], weights[N,S], depth[N], ins[N,*])``.
+
+    ``manipulator=False`` restates ``render_train`` (networks/render.py:6-28): instance map is
+    ``sigmoid(sum_i w_i.detach() * logits_i)`` with the last ("air") channel dropped.
+    ``manipulator=True`` restates ``manipulator_render`` (networks/manipulator.py:86-105):
+    no detach and all ``ins_num+1`` channels kept.
+    """
+    delta = z[..., 1:] - z[..., :-1]
+    delta = torch.cat([delta, torch.full_like(delta[..., :1], 1e10)], -1)
+    delta = delta * torch.norm(rays_d[..., None, :], dim=-1)
+    colour = torch.sigmoid(raw[..., :3])
+    alpha = 1.0 - torch.exp(-F.relu(raw[..., 3]) * delta)
+    trans = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha + 1e-10], -1), -1)[:, :-1]
+    weights = alpha * trans
+    rgb_map = torch.sum(weights[..., None] * colour, -2)
+    depth_map = torch.sum(weights * z, -1)
+    w_ins = weights if manipulator else weights.detach()
+    ins_map = torch.sigmoid(torch.sum(w_ins[..., None] * raw[..., 4:], -2))
+    if not manipulator:
+        ins_map = ins_map[..., :-1]
+    return rgb_map, weights, depth_map, ins_map
+
+
+def inverse_cdf(bins: torch.Tensor, weights: torch.Tensor, n_new: int, det: bool,
+                u: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Hierarchical sampler (``sample_pdf``, networks/helpers.py:123-155).
+
+    ``u`` overrides the uniform draws when ``det`` is False (the reference calls the global
+    ``torch.rand``; parity tests record its output and pass it here)."""
+    w = weights + 1e-5
+    pdf = w / torch.sum(w, -1, keepdim=True)
+    cdf = torch.cumsum(pdf, -1)
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
+    if det:
+        u = torch.linspace(0.0, 1.0, steps=n_new).expand(*cdf.shape[:-1], n_new)
+    elif u is None:
+        u = torch.rand(*cdf.shape[:-1], n_new)
+    u = u.contiguous()
+    idx = torch.searchsorted(cdf, u, right=True)
+    lo = torch.clamp(idx - 1, min=0)
+    hi = torch.clamp(idx, max=cdf.shape[-1] - 1)
+    cdf_lo, cdf_hi = torch.gather(cdf, -1, lo), torch.gather(cdf, -1, hi)
+    bin_lo, bin_hi = torch.gather(bins, -1, lo), torch.gather(bins, -1, hi)
+    den = cdf_hi - cdf_lo
+    den = torch.where(den < 1e-5, torch.ones_like(den), den)
+    t = (u - cdf_lo) / den
+    return bin_lo + t * (bin_hi - bin_lo)
+
+
+def merge_depths(z_coarse: torch.Tensor, z_new: torch.Tensor) -> torch.Tensor:
+    """Ascending merge of coarse and resampled depths (networks/render.py:70)."""
+    return torch.sort(torch.cat([z_coarse, z_new], -1), -1).values
+
+
+# --------------------------------------------------------------------------------------
+# the render call
+# --------------------------------------------------------------------------------------
+def render_rays(rays: torch.Tensor, coarse: Params, fine: Params, z_coarse: torch.Tensor,
+                n_importance: int = 128, perturb: float = 0.0,
+                t_rand: Optional[torch.Tensor] = None, u: Optional[torch.Tensor] = None,
+                n_ins: Optional[int] = None) -> Dict[str, torch.Tensor]:
+    """One chunk of rays through coarse field -> composite -> resample -> fine field ->
+    composite.  Restates ``dm_nerf`` (networks/render.py:31-96); returns its 10-key dict plus
+    ``weights_coarse`` / ``weights_fine`` (extra keys, used by stage-wise parity tests)."""
+    rays_o, rays_d = rays[0], rays[1]
+    if perturb > 0.0:
+        if t_rand is None:
+            t_rand = torch.rand(z_coarse.shape)
+        z_coarse = jitter_depths(z_coarse, t_rand)
+    raw_c = field_on_rays(coarse, rays_o, rays_d, z_coarse)
+    rgb_c, w_c, depth_c, ins_c = composite(raw_c, z_coarse, rays_d)
+    mid = 0.5 * (z_coarse[..., 1:] + z_coarse[..., :-1])
+    z_new = inverse_cdf(mid, w_c[..., 1:-1], n_importance, det=(perturb == 0.0), u=u).detach()
+    z_fine = merge_depths(z_coarse, z_new)
+    raw_f = field_on_rays(fine, rays_o, rays_d, z_fine)
+    rgb_f, w_f, depth_f, ins_f = composite(raw_f, z_fine, rays_d)
+    if n_ins is not None:                                                  # render.py:88-90
+        ins_f, ins_c = ins_f[-n_ins:], ins_c[-n_ins:]
+    return {"rgb_fine": rgb_f, "ins_fine": ins_f, "z_vals_fine": z_fine, "raw_fine": raw_f,
+            "raw_coarse": raw_c, "rgb_coarse": rgb_c, "ins_coarse": ins_c, "z_vals_coarse": z_coarse,
+            "depth_fine": depth_f, "depth_coarse": depth_c,
+            "weights_coarse": w_c, "weights_fine": w_f}
+
+
+def render_image(H: int, W: int, K, c2w: torch.Tensor, coarse: Params, fine: Params,
+                 near: float, far: float, n_samples: int = 64, n_importance: int = 128,
+                 chunk: int = 4096, max_rays: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Full-image render in ``chunk``-ray pieces with a ragged tail; returns
+    ``(rgb[H,W,3], ins[H,W,ins_num])``.  Restates the chunk loop of ``render_test``
+    (networks/tester.py:57-85, no crop mask).  ``max_rays`` truncates the loop (used by the
+    bounded CPU-baseline timing); the outputs are then flat ``[max_rays, .]``."""
+    z = coarse_depths(chunk, near, far, n_samples)
+    rays_o, rays_d = rays_from_camera(H, W, K, c2w)
+    rays_o = rays_o.reshape(-1, 3).float()
+    rays_d = rays_d.reshape(-1, 3).float()
+    total = H * W if max_rays is None else min(max_rays, H * W)
+    rgbs, inss = [], []
+    with torch.no_grad():
+        for start in range(0, total, chunk):
+            n = min(chunk, total - start)
+            if n != z.shape[0]:
+                z = coarse_depths(n, near, far, n_samples)
+            out = render_rays(torch.stack([rays_o[start:start + n], rays_d[start:start + n]], 0),
+                              coarse, fine, z, n_importance=n_importance, perturb=0.0)
+            rgbs.append(out["rgb_fine"])
+            inss.append(out["ins_fine"])
+    rgb, ins = torch.cat(rgbs, 0), torch.cat(inss, 0)
+    if max_rays is None:
+        rgb, ins = rgb.reshape(H, W, 3), ins.reshape(H, W, ins.shape[-1])
+    return rgb, ins
+
+
+# --------------------------------------------------------------------------------------
+# synthetic cameras (conventions of datasets/loader_dmsr.py:29-34,171-172)
+# --------------------------------------------------------------------------------------
+def dmsr_intrinsics(H: int, W: int, camera_angle_x: float = 0.6911) -> np.ndarray:
+    f = 0.5 * W / math.tan(0.5 * camera_angle_x)
+    return np.array([[f, 0.0, W / 2.0], [0.0, -f, H / 2.0], [0.0, 0.0, -1.0]], dtype=np.float64)
+
+
+def pose_spherical(theta_deg: float, phi_deg: float, radius: float) -> np.ndarray:
+    """Blender-style orbit pose (datasets/loader_dmsr.py:10-34)."""
+    t = np.eye(4); t[2, 3] = radius
+    p = math.radians(phi_deg)
+    rp = np.array([[1, 0, 0, 0], [0, math.cos(p), -math.sin(p), 0], [0, math.sin(p), math.cos(p), 0], [0, 0, 0, 1.0]])
+    th = math.radians(theta_deg)
+    rt = np.array([[math.cos(th), 0, -math.sin(th), 0], [0, 1, 0, 0], [math.sin(th), 0, math.cos(th), 0], [0, 0, 0, 1.0]])
+    flip = np.array([[-1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1.0]])
+    return (flip @ rt @ rp @ t).astype(np.float32)
+
+
+def study_pose(index: int = 0) -> np.ndarray:
+    """Pose 0 = identity rotation at (0.3,-0.2,6.0); poses 1..7 orbit at phi=-65deg, r=7."""
+    if index == 0:
+        c2w = np.eye(4, dtype=np.float32)
+        c2w[:3, 3] = (0.3, -0.2, 6.0)
+        return c2w
+    return pose_spherical(-180.0 + 45.0 * index, -65.0, 7.0)

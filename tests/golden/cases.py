@@ -1,0 +1,119 @@
+"""Seeded input builders shared by ``make_golden.py`` (which feeds them to the reference)
+and by the tests (which feed them to the oracle and to the HIP path).  Inputs are regenerated
+from numpy PCG64 seeds on both sides; the fixtures store an ``input_digest`` so a drift in
+the generator would be detected instead of silently comparing different inputs."""
+from __future__ import annotations
+
+import hashlib
+import math
+
+import numpy as np
+
+NEAR, FAR = 4.0, 15.0          # configs/test/dmsr/study.txt:13-14
+N_SAMPLES, N_IMPORTANCE = 64, 128
+
+
+def digest(*arrays) -> str:
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()[:16]
+
+
+# ---- G1: cameras -------------------------------------------------------------------
+def camera_cases():
+    """Three intrinsics conventions at H=6, W=8 plus one non-trivial pose."""
+    H, W = 6, 8
+    f = 0.5 * W / math.tan(0.5 * 0.6911)
+    k_dmsr = np.array([[f, 0, W * 0.5], [0, -f, H * 0.5], [0, 0, -1]], dtype=np.float64)
+    k_replica = np.array([[W / 2.0, 0, (W - 1) / 2.0], [0, W / 2.0, (H - 1) / 2.0], [0, 0, 1]], dtype=np.float64)
+    k_scannet = np.array([[577.87, 0, 319.5, 0], [0, 577.87, 239.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float64)
+    rng = np.random.default_rng(11)
+    q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    c2w = np.eye(4, dtype=np.float32)
+    c2w[:3, :3] = q.astype(np.float32)
+    c2w[:3, 3] = (0.3, -0.2, 6.0)
+    return H, W, {"dmsr": k_dmsr, "replica": k_replica, "scannet": k_scannet}, c2w
+
+
+# ---- G2: encoder inputs ------------------------------------------------------------
+def encoder_points():
+    rng = np.random.default_rng(12)
+    x = rng.uniform(-4.0, 4.0, size=(256, 3)).astype(np.float32)
+    x[:32] *= 3.75                      # |x| up to 15 -> arguments up to ~7.7e3 rad at 2^9
+    x[32:40] = 0.0
+    x[40, :] = (15.0, -15.0, 14.999)
+    x[41, :] = (1e-6, -1e-6, 3.1415927)
+    v = rng.standard_normal((256, 3)).astype(np.float32)
+    v /= np.linalg.norm(v, axis=-1, keepdims=True)
+    return x, v.astype(np.float32)
+
+
+# ---- G3: field inputs --------------------------------------------------------------
+def field_rows():
+    """256 embedded rows are built from these points/dirs by the side under test."""
+    rng = np.random.default_rng(13)
+    x = rng.uniform(-9.0, 9.0, size=(256, 3)).astype(np.float32)
+    v = rng.standard_normal((256, 3)).astype(np.float32)
+    v /= np.linalg.norm(v, axis=-1, keepdims=True)
+    return x, v.astype(np.float32)
+
+
+# ---- G4: compositing inputs --------------------------------------------------------
+def composite_case(n_rays: int, n_samples: int, channels: int, seed: int):
+    rng = np.random.default_rng(seed)
+    raw = rng.standard_normal((n_rays, n_samples, channels)).astype(np.float32) * 2.0
+    raw[..., 3] *= 4.0                                    # densities: mixture of <0 and large
+    raw[0, :, 3] = -1.0                                   # fully transparent ray
+    raw[1, :, 3] = 1e4                                    # saturated alpha from the first sample
+    raw[2, : n_samples // 2, 3] = -3.0                    # empty then dense
+    z = np.sort(rng.uniform(NEAR, FAR, size=(n_rays, n_samples)).astype(np.float32), axis=-1)
+    z[3] = np.linspace(NEAR, FAR, n_samples, dtype=np.float32)
+    z[4, 10:14] = z[4, 10]                                # repeated depths -> zero-length intervals
+    d = rng.standard_normal((n_rays, 3)).astype(np.float32)
+    d[5] *= 1e-3
+    return raw, z, d
+
+
+# ---- G5: sampler inputs ------------------------------------------------------------
+def sampler_case(n_rays: int = 48, seed: int = 15):
+    rng = np.random.default_rng(seed)
+    z = np.linspace(NEAR, FAR, N_SAMPLES, dtype=np.float32)[None].repeat(n_rays, 0)
+    z[n_rays // 2:] += rng.uniform(0, 0.05, size=(n_rays - n_rays // 2, N_SAMPLES)).astype(np.float32)
+    z = np.sort(z, -1)
+    bins = 0.5 * (z[:, 1:] + z[:, :-1])
+    w = rng.uniform(0, 1, size=(n_rays, N_SAMPLES - 2)).astype(np.float32) ** 8
+    w[0] = 0.0                                            # all-zero weights -> uniform pdf
+    w[1] = 0.0; w[1, 20] = 1.0                            # single peak
+    w[2] = 0.0; w[2, 0] = 0.7; w[2, -1] = 0.3             # mass at both ends
+    w[3] = 1.0                                            # flat
+    u = rng.uniform(0, 1, size=(n_rays, N_IMPORTANCE)).astype(np.float32)
+    u[4, :4] = (0.0, 0.99999994, 0.5, 1e-7)
+    return bins.astype(np.float32), w, u
+
+
+# ---- G6/G8: rays for whole-path cases ----------------------------------------------
+def study_intrinsics(H: int, W: int) -> np.ndarray:
+    f = 0.5 * W / math.tan(0.5 * 0.6911)
+    return np.array([[f, 0.0, W / 2.0], [0.0, -f, H / 2.0], [0.0, 0.0, -1.0]], dtype=np.float64)
+
+
+def study_c2w() -> np.ndarray:
+    c2w = np.eye(4, dtype=np.float32)
+    c2w[:3, 3] = (0.3, -0.2, 6.0)
+    return c2w
+
+
+def path_rays(n_rays: int, seed: int = 16):
+    """Random subset of the 800x800 'study' camera's rays (computed in float64 -> fp32 here so
+    that ray generation is not part of this case)."""
+    H = W = 800
+    K = study_intrinsics(H, W)
+    rng = np.random.default_rng(seed)
+    pix = rng.choice(H * W, size=n_rays, replace=False)
+    r, c = pix // W, pix % W
+    d = np.stack([(c - K[0, 2]) / K[0, 0], (r - K[1, 2]) / K[1, 1], np.full(n_rays, K[2, 2])], -1)
+    o = np.broadcast_to(study_c2w()[:3, 3], d.shape)
+    t_rand = rng.uniform(0, 1, size=(n_rays, N_SAMPLES)).astype(np.float32)
+    u = rng.uniform(0, 1, size=(n_rays, N_IMPORTANCE)).astype(np.float32)
+    return o.astype(np.float32).copy(), d.astype(np.float32), t_rand, u

@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under ``tests/golden/*.npz`` by running the REFERENCE itself.
+
+Run only in the build container (needs ``/root/reference``; the reference never travels):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+It imports ``networks.{dm_nerf,helpers,render}`` from the reference tree, feeds them the
+seeded inputs of ``cases.py`` and synthetic weights from ``oracle.make_params`` (weights
+are regenerated from the seed on the test side, so they are not stored), and writes the
+reference's outputs.  Stochastic paths are made reproducible by substituting
+``torch.rand`` with a queue of recorded tensors while the reference runs.
+
+``config.create_nerf`` (needs configargparse) and ``tester.render_test`` (needs cv2/lpips)
+do not import in this image; their few relevant lines are re-enacted below from
+config.py:150-157 and networks/tester.py:57-85.
+"""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+sys.dont_write_bytecode = True
+REF = os.environ.get("DMNERF_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+
+import cases  # noqa: E402
+from oracle import dmnerf_cpu as oracle  # noqa: E402  (only make_params is used)
+
+from networks import dm_nerf as ref_model  # noqa: E402
+from networks import helpers as ref_helpers  # noqa: E402
+from networks import render as ref_render  # noqa: E402
+
+torch.autograd.set_detect_anomaly(False)   # undo the import side effect of networks/dm_nerf.py:5
+torch.manual_seed(0)
+
+
+class RandQueue:
+    """Stand-in for ``torch.rand`` that hands out pre-recorded tensors in call order."""
+
+    def __init__(self, tensors):
+        self.tensors = list(tensors)
+        self._orig = torch.rand
+
+    def __call__(self, *size, **kw):
+        t = self.tensors.pop(0)
+        shape = tuple(size[0]) if len(size) == 1 and not isinstance(size[0], int) else tuple(size)
+        assert tuple(t.shape) == shape, (t.shape, shape)
+        return t
+
+    def __enter__(self):
+        torch.rand = self
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand = self._orig
+        assert not self.tensors, "recorded draws left unused"
+
+
+def build_nets(ins_num, seed_c, seed_f):
+    """config.py:150-157 re-enacted."""
+    pos_enc, pos_ch = ref_model.get_embedder(10, 0)
+    dir_enc, dir_ch = ref_model.get_embedder(4, 0)
+    nets = []
+    for seed in (seed_c, seed_f):
+        net = ref_model.DM_NeRF(8, 256, pos_ch, dir_ch, [4], ins_num)
+        net.load_state_dict(oracle.make_params(ins_num, seed))
+        net.eval()
+        nets.append(net)
+    return pos_enc, dir_enc, nets[0], nets[1]
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                 for k, v in arrays.items()})
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def g1_rays():
+    H, W, Ks, c2w = cases.camera_cases()
+    out = {"input_digest": cases.digest(c2w, *[Ks[k] for k in sorted(Ks)])}
+    for name, K in Ks.items():
+        o, d = ref_helpers.get_rays_k(H, W, K, torch.from_numpy(c2w))
+        out[f"{name}_o"], out[f"{name}_d"] = o, d
+    # the training call passes poses[i,:3,:4] (train_dmsr.py:27)
+    o, d = ref_helpers.get_rays_k(H, W, Ks["dmsr"], torch.from_numpy(c2w[:3, :4]))
+    out["dmsr34_o"], out["dmsr34_d"] = o, d
+    save("g1_rays.npz", **out)
+
+
+def g2_encode():
+    x, v = cases.encoder_points()
+    pos_enc, _ = ref_model.get_embedder(10, 0)
+    dir_enc, _ = ref_model.get_embedder(4, 0)
+    save("g2_encode.npz", input_digest=cases.digest(x, v),
+         pos=pos_enc.embed(torch.from_numpy(x)), dir=dir_enc.embed(torch.from_numpy(v)))
+
+
+def g3_field():
+    x, v = cases.field_rows()
+    out = {"input_digest": cases.digest(x, v)}
+    for ins_num, seed in ((13, 0), (93, 3), (7, 4)):
+        pos_enc, dir_enc, net, _ = build_nets(ins_num, seed, seed)
+        emb = torch.cat([pos_enc.embed(torch.from_numpy(x)), dir_enc.embed(torch.from_numpy(v))], -1)
+        with torch.no_grad():
+            out[f"raw_ins{ins_num}"] = net(emb)
+    save("g3_field.npz", **out)
+
+
+def g4_composite():
+    out = {}
+    for tag, (n, s, c, seed) in {"a": (32, 64, 18, 141), "b": (16, 192, 18, 142), "c": (8, 64, 98, 143),
+                                 "d": (8, 100, 11, 144)}.items():
+        raw, z, d = cases.composite_case(n, s, c, seed)
+        rgb, w, depth, ins = ref_render.render_train(torch.from_numpy(raw), torch.from_numpy(z), torch.from_numpy(d))
+        out.update({f"{tag}_digest": cases.digest(raw, z, d), f"{tag}_rgb": rgb, f"{tag}_w": w,
+                    f"{tag}_depth": depth, f"{tag}_ins": ins})
+    save("g4_composite.npz", **out)
+
+
+def g5_sampler():
+    bins, w, u = cases.sampler_case()
+    det = ref_helpers.sample_pdf(torch.from_numpy(bins), torch.from_numpy(w), cases.N_IMPORTANCE, det=True)
+    with RandQueue([torch.from_numpy(u)]):
+        rnd = ref_helpers.sample_pdf(torch.from_numpy(bins), torch.from_numpy(w), cases.N_IMPORTANCE, det=False)
+    det40 = ref_helpers.sample_pdf(torch.from_numpy(bins), torch.from_numpy(w), 40, det=True)
+    save("g5_sampler.npz", input_digest=cases.digest(bins, w, u), det=det, rnd=rnd, det40=det40)
+
+
+def g6_path():
+    n = 128
+    o, d, t_rand, u = cases.path_rays(n)
+    rays = torch.from_numpy(np.stack([o, d], 0))
+    pos_enc, dir_enc, coarse, fine = build_nets(13, 0, 1)
+    z = ref_helpers.z_val_sample(n, cases.NEAR, cases.FAR, cases.N_SAMPLES)
+    out = {"input_digest": cases.digest(o, d, t_rand, u), "z_lattice": z[0]}
+    keep = ("rgb_fine", "ins_fine", "depth_fine", "z_vals_fine", "rgb_coarse", "ins_coarse", "depth_coarse",
+            "z_vals_coarse")
+    with torch.no_grad():
+        args = SimpleNamespace(perturb=0.0, N_importance=cases.N_IMPORTANCE, is_train=False, N_ins=None)
+        res = ref_render.dm_nerf(rays, pos_enc, dir_enc, coarse, fine, z, args)
+        for k in keep:
+            out[f"det_{k}"] = res[k]
+        out["det_raw_coarse_head"] = res["raw_coarse"][:8]
+        out["det_raw_fine_head"] = res["raw_fine"][:8]
+        args = SimpleNamespace(perturb=1.0, N_importance=cases.N_IMPORTANCE, is_train=True, N_ins=None)
+        with RandQueue([torch.from_numpy(t_rand), torch.from_numpy(u)]):
+            res = ref_render.dm_nerf(rays, pos_enc, dir_enc, coarse, fine, z, args)
+        for k in keep:
+            out[f"rnd_{k}"] = res[k]
+        out["rnd_raw_fine_head"] = res["raw_fine"][:8]
+        # N_importance = 0 ("coarse-only" BASELINE config 1): fine net re-evaluates the coarse depths
+        args = SimpleNamespace(perturb=0.0, N_importance=0, is_train=False, N_ins=None)
+        res = ref_render.dm_nerf(rays[:, :32], pos_enc, dir_enc, coarse, fine, z[:32], args)
+        for k in ("rgb_fine", "ins_fine", "depth_fine", "z_vals_fine"):
+            out[f"ni0_{k}"] = res[k]
+        # ScanNet crop sampler slice (render.py:88-90)
+        args = SimpleNamespace(perturb=0.0, N_importance=cases.N_IMPORTANCE, is_train=True, N_ins=10)
+        res = ref_render.dm_nerf(rays[:, :32], pos_enc, dir_enc, coarse, fine, z[:32], args)
+        out["nins_ins_fine"], out["nins_ins_coarse"] = res["ins_fine"], res["ins_coarse"]
+    save("g6_path.npz", **out)
+
+
+def g8_image():
+    """networks/tester.py:57-85 re-enacted at 20x24 with N_test=100 (ragged tail of 80)."""
+    H, W, n_test = 20, 24, 100
+    K, c2w = cases.study_intrinsics(H, W), cases.study_c2w()
+    pos_enc, dir_enc, coarse, fine = build_nets(13, 0, 1)
+    args = SimpleNamespace(perturb=0.0, N_importance=cases.N_IMPORTANCE, is_train=False, N_ins=None,
+                           N_test=n_test, near=cases.NEAR, far=cases.FAR, N_samples=cases.N_SAMPLES)
+    with torch.no_grad():
+        rays_o, rays_d = ref_helpers.get_rays_k(H, W, K, torch.Tensor(c2w))
+        flat = torch.stack([rays_o.reshape(-1, 3).float(), rays_d.reshape(-1, 3).float()], 0)
+        rgb_parts, ins_parts = [], []
+        for piece in torch.split(flat, n_test, dim=1):          # 100,100,100,100,80 rays
+            z = ref_helpers.z_val_sample(piece.shape[1], args.near, args.far, args.N_samples)
+            info = ref_render.dm_nerf(piece, pos_enc, dir_enc, coarse, fine, z, args)
+            rgb_parts.append(info["rgb_fine"])
+            ins_parts.append(info["ins_fine"])
+    save("g8_image.npz", rgb=torch.cat(rgb_parts).reshape(H, W, 3), ins=torch.cat(ins_parts).reshape(H, W, -1))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g8"]
+    table = {"g1": g1_rays, "g2": g2_encode, "g3": g3_field, "g4": g4_composite, "g5": g5_sampler,
+             "g6": g6_path, "g8": g8_image}
+    for key in which:
+        table[key]()

@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rays/s for an 800x800 render of the DM-SR 'study' configuration
+(64 coarse + 128 importance samples, 8x256 field with ins_num = 13 instance head) through the
+HIP hot path, plus the roofline of the dominant kernel and the CPU oracle timed beside it.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one full 800x800 image (640,000 rays) rendered through ``dm_nerf_amd.render_image``
+(ray generation -> per chunk: coarse field, composite, resample+merge, fine field, composite).
+Inputs are synthetic (no dataset / checkpoint exists offline): DM-SR style intrinsics, orbit
+poses, PCG64-seeded weights.  With N > 1 (launched by torch.distributed.run,
+one process per GPU) every rank renders its own pose: no data-path collective, weak scaling.
+
+Prints ONE JSON line on rank 0."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import dm_nerf_amd as dm  # noqa: E402
+from dm_nerf_amd import ops  # noqa: E402
+
+H = W = 800
+INS_NUM = 13
+N_SAMPLES, N_IMPORTANCE = 64, 128
+MACS_PER_POINT = 693_504                       # BASELINE.md section 3 (networks/dm_nerf.py:65-78)
+FLOP_PER_POINT = 2 * MACS_PER_POINT
+PEAK_F32_MFMA_TFLOPS = 157.3                   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0                          # MI355X_MICROARCH.md: HBM3E spec
+
+
+def composite_bytes(n_rays: int, s: int, c: int) -> int:
+    # raw S*C*4 + z S*4 + d 12 in; w S*4 + rgb 12 + depth 4 + ins 4*ins_num out
+    return n_rays * (s * c * 4 + s * 4 + 12 + s * 4 + 12 + 4 + 4 * (c - 5))
+
+
+def synthetic_scene(device):
+    """Weights and cameras of the synthetic 'study' workload.  The weight tensors come from the
+    oracle module's seeded generator (data only, shared with the parity tests)."""
+    from oracle import dmnerf_cpu as oracle
+    args = dm.default_args(ins_num=INS_NUM, N_samples=N_SAMPLES, N_importance=N_IMPORTANCE, N_test=4096,
+                           near=4.0, far=15.0, device=device)
+    pos, view, coarse, fine, args = dm.create_nerf(args)
+    params = oracle.make_params(INS_NUM, 0), oracle.make_params(INS_NUM, 1)
+    coarse.load_state_dict(params[0])
+    fine.load_state_dict(params[1])
+    K = oracle.dmsr_intrinsics(H, W)
+    poses = [oracle.study_pose(i) for i in range(8)]
+    return (pos, view, coarse.eval(), fine.eval(), args), K, poses, params
+
+
+def cpu_baseline(K, pose, params, sample_rays: int, chunk: int):
+    """The CPU oracle (port of the reference's PyTorch-CPU path) on a bounded sample of the same
+    workload: the first `sample_rays` rays of the image in `chunk`-ray pieces, after one warm-up."""
+    from oracle import dmnerf_cpu as oracle
+    torch.set_num_threads(os.cpu_count() or 1)
+    c2w = torch.from_numpy(pose)
+    oracle.render_image(H, W, K, c2w, params[0], params[1], 4.0, 15.0, N_SAMPLES, N_IMPORTANCE, chunk=256,
+                        max_rays=256)
+    t0 = time.perf_counter()
+    rgb, ins = oracle.render_image(H, W, K, c2w, params[0], params[1], 4.0, 15.0, N_SAMPLES, N_IMPORTANCE,
+                                   chunk=chunk, max_rays=sample_rays)
+    dt = time.perf_counter() - t0
+    return sample_rays / dt, rgb, ins
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--chunk", type=int, default=4096, help="rays per dm_nerf call (configs: N_test = 4096)")
+    ap.add_argument("--cpu-rays", type=int, default=8192, help="rays of the CPU-baseline sample (0 = skip)")
+    ns = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != ns.gpus:
+        raise SystemExit(f"--gpus {ns.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    dm.load_library()
+    nerf, K, poses, params = synthetic_scene(device)
+    pos, view, coarse, fine, args = nerf
+    pose = poses[rank % len(poses)]
+    hwk = [H, W, K]
+
+    def step():
+        return dm.render_image(pos, view, coarse, fine, pose, hwk, args, chunk=ns.chunk)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(ns.warmup):
+        step()
+    barrier()
+    ops.PROFILE = []
+    t0 = time.perf_counter()
+    for _ in range(ns.steps):
+        rgb, ins = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    profile, ops.PROFILE = ops.PROFILE, None
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    rays_total = world * ns.steps * H * W
+    value = rays_total / elapsed
+
+    # per-kernel durations from HIP events recorded on the launch stream inside the timed region
+    def kernel_stats(name):
+        rows = [(a.elapsed_time(b) * 1e-3, work) for k, a, b, work in profile if k == name]
+        secs = float(sum(r[0] for r in rows))
+        return len(rows), secs, int(sum(r[1] for r in rows))
+
+    n_f, t_f, pts_f = kernel_stats("field_fwd")
+    n_c, t_c, pts_c = kernel_stats("composite")
+    field_tflops = pts_f * FLOP_PER_POINT / t_f / 1e12
+    c_ch = 5 + INS_NUM
+    # composite launches alternate S=64 and S=192 with the same ray count; bytes by sample total
+    comp_bytes = (pts_c // (N_SAMPLES + N_SAMPLES + N_IMPORTANCE)) * (
+        composite_bytes(1, N_SAMPLES, c_ch) + composite_bytes(1, N_SAMPLES + N_IMPORTANCE, c_ch))
+    comp_gbs = comp_bytes / t_c / 1e9
+
+    out = {
+        "metric": "rays/sec, DM-SR study 800x800, 64+128 samples (PSNR vs reference path in `psnr_vs_cpu_oracle_db`)",
+        "value": value, "unit": "rays/s", "n_gpus": world, "steps": ns.steps, "warmup": ns.warmup,
+        "ms_per_step": elapsed / ns.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "DM-SR 'study' 800x800, 64+128 hierarchical, 8x256 field, RGB+sigma+instance head "
+                               "(ins_num=13), 1 image per GPU per step", "chunk_rays": ns.chunk,
+                   "parallelism": f"ray/image-sharded x{world}, no collective"},
+        "roofline": {"kernel": "field_fwd_kernel<1> (fused encodings + 8x256 field, fp32 MFMA)", "bound": "mfma",
+                     "achieved": field_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": field_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                     "launches": n_f, "avg_launch_ms": t_f / max(n_f, 1) * 1e3,
+                     "algorithmic_flop_per_launch": pts_f * FLOP_PER_POINT / max(n_f, 1),
+                     "time_share_of_step": t_f / elapsed},
+        "roofline_composite": {"kernel": "composite_kernel (LDS-staged slabs + wave product scan)", "bound": "hbm",
+                               "achieved": comp_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                               "frac": comp_gbs / PEAK_HBM_GBS, "traffic": None, "launches": n_c,
+                               "avg_launch_ms": t_c / max(n_c, 1) * 1e3, "time_share_of_step": t_c / elapsed},
+    }
+
+    if ns.cpu_rays > 0:
+        cpu_rps, cpu_rgb, cpu_ins = cpu_baseline(K, pose, params, ns.cpu_rays, ns.chunk)
+        got = rgb.reshape(-1, 3)[: ns.cpu_rays].cpu()
+        mse = float(torch.mean((got - cpu_rgb) ** 2))
+        out["psnr_vs_cpu_oracle_db"] = float(-10.0 * np.log10(max(mse, 1e-20)))
+        out["max_abs_err_rgb_vs_cpu_oracle"] = float((got - cpu_rgb).abs().max())
+        out["cpu_baseline"] = {
+            "value": cpu_rps, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"first {ns.cpu_rays} rays of the same 800x800 image in {ns.chunk}-ray chunks through "
+                      "oracle/dmnerf_cpu.py (PyTorch CPU fp32, same op sequence as the reference), after a "
+                      "256-ray warm-up"}
+        out["gpu_over_cpu"] = value / cpu_rps
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,28 @@
+"""dm_nerf_amd -- MI355X-native (gfx950) volumetric-render hot path behind DM-NeRF's Python API.
+
+Exports the reference's names (SURVEY.md name map): ``create_nerf``, ``get_embedder``,
+``DM_NeRF``, ``dm_nerf``, ``render_train``, ``render_test``, ``sample_pdf``, ``z_val_sample``,
+``get_rays_k``, ``manipulator_nerf``, ``manipulator_render``; plus the nerf-pytorch aliases the
+north-star uses (``render``, ``raw2outputs``, ``render_path``, ``get_rays``-style names).
+
+All compute runs in hand-written HIP kernels loaded from ``csrc/libdmnerf_hip.so`` through the
+C ABI of ``include/dmnerf_hip.h``.  There is no CPU fallback: without the library or without a
+ROCm device the calls raise."""
+from ._lib import HipLibraryError, LIB_PATH, load as load_library
+from .config import create_nerf, default_args
+from .dm_nerf import DM_NeRF, Embedder, get_embedder
+from .helpers import get_rays_k, sample_pdf, z_val_sample
+from .manipulator import manipulator_nerf, manipulator_render
+from .render import dm_nerf, render_train
+from .tester import render_image, render_test
+
+# nerf-pytorch names used by BASELINE.json's north_star
+render = dm_nerf
+raw2outputs = render_train
+render_path = render_test
+
+__all__ = [
+    "HipLibraryError", "LIB_PATH", "load_library", "create_nerf", "default_args", "DM_NeRF", "Embedder",
+    "get_embedder", "get_rays_k", "sample_pdf", "z_val_sample", "manipulator_nerf", "manipulator_render",
+    "dm_nerf", "render_train", "render_image", "render_test", "render", "raw2outputs", "render_path",
+]

@@ -1,0 +1,396 @@
+// Fused field evaluation for gfx950 (MI355X): sample points -> positional / view encodings ->
+// the whole DM-NeRF network (8x256 trunk with skip, density head, view-dependent colour branch,
+// instance-code branch) in ONE kernel, on v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma
+// chain).  Replaces networks/render.py:37-38,49-61 (+ :71-83) and networks/dm_nerf.py:80-106 of
+// the reference; no intermediate ([M,90] encodings, [M,256] activations) ever touches HBM.
+//
+// Mapping (see field_layout.h for the packed-weight side):
+//   * workgroup = 4 waves = 128 consecutive sample points; wave = 32 points; one wave per SIMD
+//     (the kernel uses the whole 512-entry register file: 128 activation + 128 accumulator
+//     registers per lane plus the encodings).
+//   * activations live in registers as H^T[feature][point] in the MFMA C/D layout and are fed
+//     back as the B operand of the next layer; weights are the A operand.
+//   * weights stream L2 -> LDS in 32 KiB stages by LDS-DMA (global_load_lds_dwordx4), double
+//     buffered, one barrier per stage (= per 128 MFMAs/wave, 8192 MFMA cycles); the 4 waves
+//     share each stage.  Algorithmic intensity vs L2 is ~64 flop/B per workgroup.
+//   * biases are the initial accumulator value; ReLU is applied when an accumulator becomes the
+//     next B operand; density (256->1) and colour (128->3) heads are VALU dot products.
+#include <hip/hip_runtime.h>
+
+#include "../../include/dmnerf_hip.h"
+#include "field_layout.h"
+#include "trig.h"
+
+using namespace dmn;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define DMN_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+namespace {
+
+struct FieldArgs {
+  const float* rays_o;   // [N,3]   (rays mode)
+  const float* rays_d;   // [N,3]
+  const float* z;        // z[n*z_stride + s]
+  long z_stride;
+  const float* emb;      // [M,90]  (embedded mode; rays_* unused)
+  const float* blob;
+  float* raw;            // [M, C]
+  long M;                // number of points
+  int S;                 // samples per ray (rays mode)
+  int ins_ch;            // ins_num + 1
+};
+
+constexpr int kLdsFloats = 2 * kStageFloats + kConstFloats;   // 80,896 B
+
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+  // LDS destination is wave-uniform base + lane*16 (hardware rule); g is per lane.
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// each wave DMA-copies 8 of the stage's 32 chunks
+__device__ __forceinline__ void load_stage(const float* stream, int g, float* buf, int wave_s, int lane) {
+  const float* src = stream + (long)g * kStageFloats + wave_s * 8 * kChunkFloats + lane * 4;
+  float* dst = buf + wave_s * 8 * kChunkFloats;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) glds16(src + q * kChunkFloats, dst + q * kChunkFloats);
+}
+
+// Barrier that retires stage g (DMA landed, everybody done with stage g-1), then prefetch of
+// stage g+1 into the other buffer.  Returns this lane's read base inside stage g.
+__device__ __forceinline__ const float* stage_begin(const float* stream, int g, int G, float* lds, int wave_s,
+                                                    int lane) {
+  __syncthreads();
+  if (g + 1 < G) load_stage(stream, g + 1, lds + ((g + 1) & 1) * kStageFloats, wave_s, lane);
+  return lds + (g & 1) * kStageFloats + lane * 4;
+}
+
+// slots 2.. of an encoding register file: sin (half 0) / cos (half 1) of 2^f * coordinate
+template <int NF>
+__device__ __forceinline__ void encode_regs(float* e, float x, float y, float zc, int h) {
+  e[0] = h ? zc : x;
+  e[1] = h ? 0.f : y;
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    const float sc = (float)(1 << f);           // exact power of two: x*freq is exact (dm_nerf.py:25,31)
+    e[2 + 3 * f + 0] = trig_sel(x * sc, h);
+    e[2 + 3 * f + 1] = trig_sel(y * sc, h);
+    e[2 + 3 * f + 2] = trig_sel(zc * sc, h);
+  }
+}
+
+__device__ __forceinline__ void bias_tiles8(f32x16* acc, const float* b) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(b + t * 16 + v * 4);
+      acc[t][4 * v + 0] = x.x; acc[t][4 * v + 1] = x.y; acc[t][4 * v + 2] = x.z; acc[t][4 * v + 3] = x.w;
+    }
+}
+template <int NT>
+__device__ __forceinline__ void bias_tiles(f32x16* acc, const float* b) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(b + t * 16 + v * 4);
+      acc[t][4 * v + 0] = x.x; acc[t][4 * v + 1] = x.y; acc[t][4 * v + 2] = x.z; acc[t][4 * v + 3] = x.w;
+    }
+}
+
+// 16 k-steps of an 8-tile layer out of one stage; B operand SRC(i) for k-step i
+#define DMN_STAGE8(BUF, SRC, BASE)                                                        \
+  {                                                                                       \
+    f32x4 a0 = *reinterpret_cast<const f32x4*>((BUF));                                    \
+    f32x4 a1 = *reinterpret_cast<const f32x4*>((BUF) + kChunkFloats);                     \
+    _Pragma("unroll") for (int jj = 0; jj < 16; ++jj) {                                   \
+      f32x4 n0 = a0, n1 = a1;                                                             \
+      if (jj + 1 < 16) { /* LDS reads of the next k-step fly under this k-step's MFMAs */ \
+        n0 = *reinterpret_cast<const f32x4*>((BUF) + (2 * jj + 2) * kChunkFloats);        \
+        n1 = *reinterpret_cast<const f32x4*>((BUF) + (2 * jj + 3) * kChunkFloats);        \
+      }                                                                                   \
+      __builtin_amdgcn_sched_barrier(0); /* keep the prefetch above the MFMAs */          \
+      const float bv = SRC((BASE) + jj);                                                  \
+      acc[0] = DMN_MFMA(a0.x, bv, acc[0]);                                                \
+      acc[1] = DMN_MFMA(a0.y, bv, acc[1]);                                                \
+      acc[2] = DMN_MFMA(a0.z, bv, acc[2]);                                                \
+      acc[3] = DMN_MFMA(a0.w, bv, acc[3]);                                                \
+      acc[4] = DMN_MFMA(a1.x, bv, acc[4]);                                                \
+      acc[5] = DMN_MFMA(a1.y, bv, acc[5]);                                                \
+      acc[6] = DMN_MFMA(a1.z, bv, acc[6]);                                                \
+      acc[7] = DMN_MFMA(a1.w, bv, acc[7]);                                                \
+      a0 = n0;                                                                            \
+      a1 = n1;                                                                            \
+    }                                                                                     \
+  }
+// NK k-steps of a 4-tile layer out of one stage
+#define DMN_STAGE4(BUF, SRC, BASE, NK)                                                    \
+  {                                                                                       \
+    f32x4 a0 = *reinterpret_cast<const f32x4*>((BUF));                                    \
+    f32x4 a1 = *reinterpret_cast<const f32x4*>((BUF) + kChunkFloats);                     \
+    _Pragma("unroll") for (int jj = 0; jj < (NK); jj += 2) {                              \
+      f32x4 n0 = a0, n1 = a1;                                                             \
+      if (jj + 2 < (NK)) {                                                                \
+        n0 = *reinterpret_cast<const f32x4*>((BUF) + (jj + 2) * kChunkFloats);            \
+        n1 = *reinterpret_cast<const f32x4*>((BUF) + (jj + 3) * kChunkFloats);            \
+      }                                                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                  \
+      const float b0 = SRC((BASE) + jj);                                                  \
+      const float b1 = SRC((BASE) + jj + 1);                                              \
+      acc2[0] = DMN_MFMA(a0.x, b0, acc2[0]);                                              \
+      acc2[1] = DMN_MFMA(a0.y, b0, acc2[1]);                                              \
+      acc2[2] = DMN_MFMA(a0.z, b0, acc2[2]);                                              \
+      acc2[3] = DMN_MFMA(a0.w, b0, acc2[3]);                                              \
+      acc2[0] = DMN_MFMA(a1.x, b1, acc2[0]);                                              \
+      acc2[1] = DMN_MFMA(a1.y, b1, acc2[1]);                                              \
+      acc2[2] = DMN_MFMA(a1.z, b1, acc2[2]);                                              \
+      acc2[3] = DMN_MFMA(a1.w, b1, acc2[3]);                                              \
+      a0 = n0;                                                                            \
+      a1 = n1;                                                                            \
+    }                                                                                     \
+  }
+
+#define SRC_ACT(i) act[(i)]
+#define SRC_PE(i) pe[(i)]
+#define SRC_QE(i) qe[(i)]
+#define SRC_ACC(i) acc[(i) >> 4][(i) & 15]
+#define SRC_ACC2(i) acc2[(i) >> 4][(i) & 15]
+
+template <int T>
+__global__ __launch_bounds__(256, 1) void field_fwd_kernel(const FieldArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
+  float* const cst = lds + 2 * kStageFloats;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, p = lane & 31, h = lane >> 5;
+  const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float* const stream = a.blob + kConstFloats;
+  constexpr int G = total_stages(T);
+
+  // const section + stage 0 start streaming while the encodings are computed
+  for (int c = wave_s; c < kConstChunks; c += 4)
+    glds16(a.blob + c * kChunkFloats + lane * 4, cst + c * kChunkFloats);
+  load_stage(stream, 0, lds, wave_s, lane);
+
+  const long m = ((long)blockIdx.x * 4 + wave_s) * 32 + p;
+  const bool valid = m < a.M;
+  const long mc = valid ? m : a.M - 1;
+
+  float pe[32], qe[16];
+  if (a.emb != nullptr) {
+    const float* row = a.emb + mc * (kPosCh + kDirCh);
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const int s0 = pos_slot(j, 0), s1 = pos_slot(j, 1);
+      const int s = h ? s1 : s0;
+      pe[j] = s >= 0 ? row[s >= 0 ? s : 0] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int s0 = dir_slot(j, 0), s1 = dir_slot(j, 1);
+      const int s = h ? s1 : s0;
+      qe[j] = s >= 0 ? row[kPosCh + (s >= 0 ? s : 0)] : 0.f;
+    }
+  } else {
+    const long n = mc / a.S;
+    const int s = (int)(mc - n * a.S);
+    const float ox = a.rays_o[3 * n + 0], oy = a.rays_o[3 * n + 1], oz = a.rays_o[3 * n + 2];
+    const float dx = a.rays_d[3 * n + 0], dy = a.rays_d[3 * n + 1], dz = a.rays_d[3 * n + 2];
+    const float zv = a.z[n * a.z_stride + s];
+    // pts = rays_o + rays_d * z: separately rounded multiply and add, as torch does (render.py:49).
+    // The 2^9 band magnifies a 1-ulp difference in pts to ~5e-4 rad, so no fma contraction here.
+    const float px = __fadd_rn(ox, __fmul_rn(dx, zv));
+    const float py = __fadd_rn(oy, __fmul_rn(dy, zv));
+    const float pz = __fadd_rn(oz, __fmul_rn(dz, zv));
+    // viewdirs = rays_d / ||rays_d|| (render.py:37)
+    const float nrm = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+    const float vx = __fdiv_rn(dx, nrm), vy = __fdiv_rn(dy, nrm), vz = __fdiv_rn(dz, nrm);
+    encode_regs<kPosFreqs>(pe, px, py, pz, h);
+    encode_regs<kDirFreqs>(qe, vx, vy, vz, h);
+    qe[14] = 0.f;
+    qe[15] = 0.f;
+  }
+
+  f32x16 acc[8];
+  float act[128];
+  int g = 0;
+  const float* buf;
+
+  // ---- mlps.0: 63 -> 256 (32 k-steps from the position encoding)
+  buf = stage_begin(stream, g, G, lds, wave_s, lane);
+  bias_tiles8(acc, cst + kConstBias8 + h * 128);
+  DMN_STAGE8(buf, SRC_PE, 0)
+  ++g;
+  buf = stage_begin(stream, g, G, lds, wave_s, lane);
+  DMN_STAGE8(buf, SRC_PE, 16)
+  ++g;
+#pragma unroll
+  for (int i = 0; i < 128; ++i) act[i] = fmaxf(acc[i >> 4][i & 15], 0.f);
+
+  // ---- mlps.1 .. mlps.7 (mlps.5 also consumes the position encoding: skip connection)
+#pragma unroll 1
+  for (int l = 1; l < kDepth; ++l) {
+    bias_tiles8(acc, cst + kConstBias8 + l * 256 + h * 128);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      buf = stage_begin(stream, g, G, lds, wave_s, lane);
+      DMN_STAGE8(buf, SRC_ACT, 16 * s)
+      ++g;
+    }
+    if (l == kSkipLayer) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        buf = stage_begin(stream, g, G, lds, wave_s, lane);
+        DMN_STAGE8(buf, SRC_PE, 16 * s)
+        ++g;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 128; ++i) act[i] = fmaxf(acc[i >> 4][i & 15], 0.f);
+  }
+
+  // ---- density_linear: 256 -> 1 on the VALU (dm_nerf.py:101)
+  float sigma = 0.f;
+  {
+    const float* w = cst + kConstDensW + h * 128;
+#pragma unroll
+    for (int i = 0; i < 128; ++i) sigma = fmaf(act[i], w[i], sigma);
+    sigma += __shfl_xor(sigma, 32);
+    sigma += cst[kConstDensB];
+  }
+
+  // ---- rgb_feature_linear: 256 -> 256, no activation (dm_nerf.py:89)
+  bias_tiles8(acc, cst + kConstBias8 + 8 * 256 + h * 128);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    buf = stage_begin(stream, g, G, lds, wave_s, lane);
+    DMN_STAGE8(buf, SRC_ACT, 16 * s)
+    ++g;
+  }
+  // ---- rgb_feature_linears.0: cat([feature, dirs]) 283 -> 128, ReLU (dm_nerf.py:90-93)
+  f32x16 acc2[4];
+  bias_tiles<4>(acc2, cst + kConstBias4 + h * 64);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    buf = stage_begin(stream, g, G, lds, wave_s, lane);
+    DMN_STAGE4(buf, SRC_ACC, 32 * s, 32)
+    ++g;
+  }
+  buf = stage_begin(stream, g, G, lds, wave_s, lane);
+  DMN_STAGE4(buf, SRC_QE, 0, 16)
+  ++g;
+  // ---- rgb_linear: 128 -> 3 on the VALU (dm_nerf.py:102)
+  float rgb[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float* w = cst + kConstRgbW + c * 128 + h * 64;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) v = fmaf(fmaxf(acc2[i >> 4][i & 15], 0.f), w[i], v);
+    v += __shfl_xor(v, 32);
+    rgb[c] = v + cst[kConstRgbB + c];
+  }
+
+  // ---- ins_feature_linear on the same trunk output (h.detach(), dm_nerf.py:95-96), no activation
+  bias_tiles8(acc, cst + kConstBias8 + 9 * 256 + h * 128);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    buf = stage_begin(stream, g, G, lds, wave_s, lane);
+    DMN_STAGE8(buf, SRC_ACT, 16 * s)
+    ++g;
+  }
+  // ---- ins_feature_linears.0: 256 -> 128, ReLU (dm_nerf.py:97-99)
+  bias_tiles<4>(acc2, cst + kConstBias4 + 128 + h * 64);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    buf = stage_begin(stream, g, G, lds, wave_s, lane);
+    DMN_STAGE4(buf, SRC_ACC, 32 * s, 32)
+    ++g;
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[t][r] = fmaxf(acc2[t][r], 0.f);
+  // ---- ins_linear: 128 -> ins_num + 1 (dm_nerf.py:103), T output tiles
+  f32x16 acc3[T];
+  bias_tiles<T>(acc3, cst + kConstBiasO + h * 64);
+  constexpr int JS = inso_groups_per_stage(T);
+#pragma unroll
+  for (int st = 0; st < inso_stages(T); ++st) {
+    buf = stage_begin(stream, g, G, lds, wave_s, lane);
+#pragma unroll
+    for (int jl = 0; jl < JS; ++jl) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(buf + (jl * T + t) * kChunkFloats);
+        const int k0 = 4 * (st * JS + jl);
+        acc3[t] = DMN_MFMA(a0.x, SRC_ACC2(k0 + 0), acc3[t]);
+        acc3[t] = DMN_MFMA(a0.y, SRC_ACC2(k0 + 1), acc3[t]);
+        acc3[t] = DMN_MFMA(a0.z, SRC_ACC2(k0 + 2), acc3[t]);
+        acc3[t] = DMN_MFMA(a0.w, SRC_ACC2(k0 + 3), acc3[t]);
+      }
+    }
+    ++g;
+  }
+
+  // ---- raw = cat([rgb, density, ins]) (dm_nerf.py:105)
+  if (valid) {
+    const int C = 4 + a.ins_ch;
+    float* out = a.raw + m * C;
+    if (h == 0) {
+      out[0] = rgb[0];
+      out[1] = rgb[1];
+      out[2] = rgb[2];
+      out[3] = sigma;
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ch = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (ch < a.ins_ch) out[4 + ch] = acc3[t][r];
+      }
+  }
+}
+
+int launch_field(const FieldArgs& a, int ins_num, hipStream_t st) {
+  if (a.M <= 0) return DMN_OK;
+  const int T = ins_tiles(ins_num);
+  const long blocks = (a.M + 127) / 128;
+  if (blocks > 0x7fffffffL) return DMN_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)blocks), block(256);
+  switch (T) {
+    case 1: hipLaunchKernelGGL(field_fwd_kernel<1>, grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL(field_fwd_kernel<2>, grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL(field_fwd_kernel<3>, grid, block, 0, st, a); break;
+    case 4: hipLaunchKernelGGL(field_fwd_kernel<4>, grid, block, 0, st, a); break;
+    default: return DMN_ERR_UNSUPPORTED;
+  }
+  return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" int dmn_field_fwd_rays(const float* rays_o, const float* rays_d, const float* z, long z_ray_stride,
+                                  long n_rays, int n_samples, const float* blob, int ins_num, float* raw,
+                                  void* stream) {
+  if (n_rays < 0 || n_samples <= 0 || ins_num < 0 || z_ray_stride < 0) return DMN_ERR_BAD_ARG;
+  if (n_rays == 0) return DMN_OK;
+  if (!rays_o || !rays_d || !z || !blob || !raw) return DMN_ERR_BAD_ARG;
+  if (ins_tiles(ins_num) > kMaxInsTiles) return DMN_ERR_UNSUPPORTED;
+  FieldArgs a{rays_o, rays_d, z, z_ray_stride, nullptr, blob, raw, n_rays * (long)n_samples, n_samples, ins_num + 1};
+  return launch_field(a, ins_num, (hipStream_t)stream);
+}
+
+extern "C" int dmn_field_fwd_embedded(const float* embedded, long n_points, const float* blob, int ins_num,
+                                      float* raw, void* stream) {
+  if (n_points < 0 || ins_num < 0) return DMN_ERR_BAD_ARG;
+  if (n_points == 0) return DMN_OK;
+  if (!embedded || !blob || !raw) return DMN_ERR_BAD_ARG;
+  if (ins_tiles(ins_num) > kMaxInsTiles) return DMN_ERR_UNSUPPORTED;
+  FieldArgs a{nullptr, nullptr, nullptr, 0, embedded, blob, raw, n_points, 1, ins_num + 1};
+  return launch_field(a, ins_num, (hipStream_t)stream);
+}

@@ -1,0 +1,109 @@
+"""Field model and encoders with the reference's names, constructor arguments and
+``state_dict`` layout (networks/dm_nerf.py:8-106), evaluated by the fused gfx950 kernel.
+
+Unlike the reference module, importing this file has no global side effect (the reference
+switches on autograd anomaly detection at import, networks/dm_nerf.py:5)."""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+POS_CH, DIR_CH = 63, 27
+
+
+class Embedder:
+    """``Embedder(**kwargs).embed(x)`` -> ``[x, sin(2^0 x), cos(2^0 x), ...]``
+    (networks/dm_nerf.py:8-38).  Only the configuration the reference ever builds is
+    supported on the GPU: 3 input dims, input included, log-sampled bands, sin+cos."""
+
+    def __init__(self, **kwargs):
+        self.kwargs = kwargs
+        d = kwargs.get("input_dims", 3)
+        if d != 3 or not kwargs.get("include_input", True) or not kwargs.get("log_sampling", True):
+            raise NotImplementedError("dm_nerf_amd encodes 3-vectors with include_input and log sampling only")
+        self.num_freqs = int(kwargs["num_freqs"])
+        if int(kwargs.get("max_freq_log2", self.num_freqs - 1)) != self.num_freqs - 1:
+            raise NotImplementedError("bands must be 2^0 .. 2^(num_freqs-1)")
+        self.out_dim = d + 2 * d * self.num_freqs
+
+    def embed(self, inputs: torch.Tensor) -> torch.Tensor:
+        return ops.encode(inputs, self.num_freqs)
+
+    __call__ = embed
+
+
+def get_embedder(multires: int, i: int = 0):
+    """networks/dm_nerf.py:41-55.  ``i == -1`` (identity) is not used by any reference config
+    and is not supported by the fused field kernel."""
+    if i == -1:
+        raise NotImplementedError("identity embedding (i_embed=-1) is not supported by the gfx950 field kernel")
+    embedder = Embedder(include_input=True, input_dims=3, max_freq_log2=multires - 1, num_freqs=multires,
+                        log_sampling=True, periodic_fns=[torch.sin, torch.cos])
+    return embedder, embedder.out_dim
+
+
+class DM_NeRF(nn.Module):
+    """8x256 field with skip at layer 4, density head, view-dependent colour branch and detached
+    instance-code branch.  Same parameter names and shapes as the reference module
+    (networks/dm_nerf.py:59-78), so checkpoints load unchanged (train_dmsr.py:82-87).
+
+    ``forward(embedded[..., 90])`` runs the fused kernel on caller-made encodings
+    (networks/manipulator.py:125-131); the render path uses ``blob()`` and lets the kernel
+    build the encodings itself."""
+
+    def __init__(self, D=8, W=256, input_ch_pts=3, input_ch_views=3, skips=[4], ins_num=None):
+        super().__init__()
+        if (D, W, input_ch_pts, input_ch_views, list(skips)) != (8, 256, POS_CH, DIR_CH, [4]):
+            raise NotImplementedError(
+                "the gfx950 field kernel is specialised for D=8, W=256, 63+27 input channels, skips=[4] "
+                "(every configuration the reference ships: config.py:23-25,56-59,153)")
+        if ins_num is None or not (0 <= ins_num < ops.MAX_INS_CHANNELS):
+            raise ValueError(f"ins_num must be in [0, {ops.MAX_INS_CHANNELS - 1}]")
+        self.skips = list(skips)
+        self.input_ch_pts, self.input_ch_views, self.ins_num = input_ch_pts, input_ch_views, ins_num
+        self.mlps = nn.ModuleList(
+            [nn.Linear(input_ch_pts, W)]
+            + [nn.Linear(W + input_ch_pts, W) if i in skips else nn.Linear(W, W) for i in range(D - 1)])
+        self.rgb_feature_linear = nn.Linear(W, W)
+        self.ins_feature_linear = nn.Linear(W, W)
+        self.rgb_feature_linears = nn.ModuleList([nn.Linear(W + input_ch_views, W // 2)])
+        self.ins_feature_linears = nn.ModuleList([nn.Linear(W, W // 2)])
+        self.density_linear = nn.Linear(W, 1)
+        self.ins_linear = nn.Linear(W // 2, ins_num + 1)
+        self.rgb_linear = nn.Linear(W // 2, 3)
+        self._blob: Optional[torch.Tensor] = None
+        self._blob_key: Optional[Tuple] = None
+        self._index: Optional[torch.Tensor] = None
+
+    # ---- packed weights -------------------------------------------------------------------
+    def _ordered_params(self) -> List[torch.Tensor]:
+        return [p for _, p in self.named_parameters()]      # registration order = state_dict order
+
+    def blob(self) -> torch.Tensor:
+        """Device blob consumed by the field kernel; re-gathered only when a parameter changed
+        (optimizer steps and load_state_dict bump the tensors' version counters)."""
+        params = self._ordered_params()
+        dev = params[0].device
+        key = (dev, tuple((p.data_ptr(), p._version) for p in params))
+        if self._blob is None or self._blob_key != key:
+            if self._index is None or self._index.device != dev:
+                self._index = ops.pack_index(self.ins_num, dev)
+            with torch.no_grad():
+                flat = torch.cat([p.detach().reshape(-1).float() for p in params])
+            self._blob = ops.pack_blob(flat, self._index)
+            self._blob_key = key
+        return self._blob
+
+    def _refuse_grad(self):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "dm_nerf_amd: the backward kernels are not built yet; call under torch.no_grad() "
+                "(the reference's test drivers do, test_dmsr.py:16)")
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        self._refuse_grad()
+        return ops.field_embedded(x, self.blob(), self.ins_num)

@@ -1,0 +1,209 @@
+"""Tensor-level wrappers over the C ABI: argument checks on the host (shapes, dtype, device,
+strides), output allocation with torch, launch on torch's current HIP stream.
+
+Every function requires ROCm-device tensors; nothing here computes on the CPU."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, current_stream, load, ptr
+
+MAX_INS_CHANNELS = 128
+
+# Optional per-launch timing hook (bench.py): when set to a list, every field / composite launch
+# appends (kernel_name, start_event, end_event, work_items) with HIP events recorded on the launch
+# stream.  None (the default) adds nothing to the launch path.
+PROFILE = None
+
+
+class _timed:
+    def __init__(self, name: str, work: int):
+        self.name, self.work = name, work
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.t0 = torch.cuda.Event(enable_timing=True)
+            self.t1 = torch.cuda.Event(enable_timing=True)
+            self.t0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            self.t1.record()
+            PROFILE.append((self.name, self.t0, self.t1, self.work))
+        return False
+
+
+def _dev(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.HipLibraryError(f"{name} is on {t.device}: dm_nerf_amd runs on a ROCm GPU only (no CPU path)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    return t
+
+
+def _rows(z: torch.Tensor, n_rays: int, name: str) -> Tuple[torch.Tensor, int]:
+    """Depth-like [N,S] tensor -> (tensor to point at, ray stride).  An expanded lattice
+    (stride 0, as z_val_sample returns) is passed as one shared row."""
+    _dev(z, name)
+    if z.dim() != 2 or z.shape[0] != n_rays:
+        raise ValueError(f"{name} must be [{n_rays}, S], got {tuple(z.shape)}")
+    if n_rays > 1 and z.stride(0) == 0 and z.stride(1) == 1:
+        return z, 0
+    z = z.contiguous()
+    return z, z.shape[1]
+
+
+def _draws(u: Optional[torch.Tensor], n_rays: int, n_new: int):
+    """Uniform draws: None (kernel evaluates linspace), a shared [n_new] row, or [N, n_new]."""
+    if u is None or n_new == 0:
+        return None, 0
+    _dev(u, "u")
+    if u.dim() == 1:
+        if u.shape[0] != n_new:
+            raise ValueError(f"u must have {n_new} entries")
+        return u.contiguous(), 0
+    if tuple(u.shape) != (n_rays, n_new):
+        raise ValueError(f"u must be [{n_rays}, {n_new}]")
+    if n_rays > 1 and u.stride(0) == 0 and u.stride(1) == 1:
+        return u, 0
+    return u.contiguous(), n_new
+
+
+# ----------------------------------------------------------------------------------------
+def pack_index(ins_num: int, device) -> torch.Tensor:
+    lib = load()
+    n = lib.dmn_field_blob_floats(ins_num)
+    if n < 0:
+        raise ValueError(f"ins_num={ins_num} unsupported (ins_num + 1 must be <= {MAX_INS_CHANNELS})")
+    idx = np.empty(n, dtype=np.int32)
+    check(lib.dmn_field_pack_index(ins_num, idx.ctypes.data), "dmn_field_pack_index")
+    return torch.from_numpy(idx).to(device)
+
+
+def pack_blob(flat_params: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
+    _dev(flat_params, "flat_params")
+    blob = torch.empty(index.numel(), dtype=torch.float32, device=flat_params.device)
+    check(load().dmn_field_pack(ptr(flat_params), ptr(index), index.numel(), ptr(blob), current_stream()),
+          "dmn_field_pack")
+    return blob
+
+
+def raygen(H: int, W: int, K, c2w) -> Tuple[torch.Tensor, torch.Tensor]:
+    """get_rays_k; K: 3x3/4x4 array-like (host), c2w: 3x4/4x4 (host array or tensor)."""
+    K = np.asarray(K, dtype=np.float64)
+    c2w_np = (c2w.detach().cpu().numpy() if torch.is_tensor(c2w) else np.asarray(c2w)).astype(np.float32)
+    c2w_np = np.ascontiguousarray(c2w_np[:3, :4])
+    dev = torch.device("cuda", torch.cuda.current_device())
+    rays_o = torch.empty(H, W, 3, dtype=torch.float32, device=dev)
+    rays_d = torch.empty(H, W, 3, dtype=torch.float32, device=dev)
+    f32 = lambda v: float(np.float32(v))
+    check(load().dmn_raygen(H, W, f32(K[0, 0]), f32(K[0, 2]), f32(K[1, 1]), f32(K[1, 2]), f32(K[2, 2]),
+                            c2w_np.ctypes.data, ptr(rays_o), ptr(rays_d), current_stream()), "dmn_raygen")
+    return rays_o, rays_d
+
+
+def jitter_depths(z: torch.Tensor, t_rand: torch.Tensor) -> torch.Tensor:
+    n, s = z.shape
+    zz, stride = _rows(z, n, "z_vals")
+    t_rand = _dev(t_rand, "t_rand").contiguous()
+    out = torch.empty(n, s, dtype=torch.float32, device=z.device)
+    check(load().dmn_jitter_depths(ptr(zz), stride, ptr(t_rand), n, s, ptr(out), current_stream()),
+          "dmn_jitter_depths")
+    return out
+
+
+def encode(x: torch.Tensor, n_freqs: int) -> torch.Tensor:
+    _dev(x, "inputs")
+    if x.shape[-1] != 3:
+        raise ValueError("encoder input must have 3 coordinates")
+    flat = x.reshape(-1, 3).contiguous()
+    out = torch.empty(flat.shape[0], 3 + 6 * n_freqs, dtype=torch.float32, device=x.device)
+    check(load().dmn_encode(ptr(flat), flat.shape[0], n_freqs, ptr(out), current_stream()), "dmn_encode")
+    return out.reshape(*x.shape[:-1], out.shape[-1])
+
+
+def field_rays(rays_o: torch.Tensor, rays_d: torch.Tensor, z: torch.Tensor, blob: torch.Tensor,
+               ins_num: int) -> torch.Tensor:
+    n = rays_o.shape[0]
+    rays_o = _dev(rays_o, "rays_o").contiguous()
+    rays_d = _dev(rays_d, "rays_d").contiguous()
+    zz, stride = _rows(z, n, "z_vals")
+    s = z.shape[1]
+    raw = torch.empty(n, s, 5 + ins_num, dtype=torch.float32, device=rays_o.device)
+    with _timed("field_fwd", n * s):
+        check(load().dmn_field_fwd_rays(ptr(rays_o), ptr(rays_d), ptr(zz), stride, n, s, ptr(blob), ins_num,
+                                        ptr(raw), current_stream()), "dmn_field_fwd_rays")
+    return raw
+
+
+def field_embedded(embedded: torch.Tensor, blob: torch.Tensor, ins_num: int) -> torch.Tensor:
+    _dev(embedded, "embedded")
+    if embedded.shape[-1] != 90:
+        raise ValueError(f"embedded input must have 63+27 channels, got {embedded.shape[-1]}")
+    flat = embedded.reshape(-1, 90).contiguous()
+    raw = torch.empty(flat.shape[0], 5 + ins_num, dtype=torch.float32, device=embedded.device)
+    check(load().dmn_field_fwd_embedded(ptr(flat), flat.shape[0], ptr(blob), ins_num, ptr(raw), current_stream()),
+          "dmn_field_fwd_embedded")
+    return raw.reshape(*embedded.shape[:-1], raw.shape[-1])
+
+
+def composite(raw: torch.Tensor, z: torch.Tensor, rays_d: torch.Tensor, keep_last: bool = False):
+    _dev(raw, "raw")
+    n, s, c = raw.shape
+    raw = raw.contiguous()
+    zz, stride = _rows(z, n, "z_vals")
+    if z.shape[1] != s:
+        raise ValueError("raw and z_vals disagree on the sample count")
+    rays_d = _dev(rays_d, "rays_d").contiguous()
+    k = c - 4 if keep_last else c - 5
+    dev = raw.device
+    rgb = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    weights = torch.empty(n, s, dtype=torch.float32, device=dev)
+    depth = torch.empty(n, dtype=torch.float32, device=dev)
+    ins = torch.empty(n, k, dtype=torch.float32, device=dev)
+    with _timed("composite", n * s):
+        check(load().dmn_composite_fwd(ptr(raw), ptr(zz), stride, ptr(rays_d), n, s, c, int(keep_last), ptr(rgb),
+                                       ptr(weights), ptr(depth), ptr(ins), current_stream()), "dmn_composite_fwd")
+    return rgb, weights, depth, ins
+
+
+def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, n_new: int, u: Optional[torch.Tensor]) -> torch.Tensor:
+    n, b = bins.shape
+    bb, bstride = _rows(bins, n, "bins")
+    w = _dev(weights, "weights")
+    if w.shape != (n, b - 1):
+        raise ValueError(f"weights must be [{n}, {b - 1}], got {tuple(w.shape)}")
+    if w.stride(1) != 1:
+        w = w.contiguous()
+    wstride = w.stride(0) if n > 1 else b - 1
+    u, ustride = _draws(u, n, n_new)
+    out = torch.empty(n, n_new, dtype=torch.float32, device=bins.device)
+    check(load().dmn_sample_pdf(ptr(bb), bstride, ptr(w), wstride, ptr(u), ustride, n, b, n_new, ptr(out),
+                                current_stream()), "dmn_sample_pdf")
+    return out
+
+
+def resample_merge(z: torch.Tensor, weights: torch.Tensor, n_new: int, u: Optional[torch.Tensor]) -> torch.Tensor:
+    n, s = z.shape
+    zz, stride = _rows(z, n, "z_vals")
+    weights = _dev(weights, "weights").contiguous()
+    u, ustride = _draws(u, n, n_new)
+    out = torch.empty(n, s + n_new, dtype=torch.float32, device=z.device)
+    check(load().dmn_resample_merge(ptr(zz), stride, ptr(weights), ptr(u), ustride, n, s, n_new, ptr(out),
+                                    current_stream()), "dmn_resample_merge")
+    return out
+
+
+def merge_depths(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    n = a.shape[0]
+    aa, astride = _rows(a, n, "a")
+    bb, bstride = _rows(b, n, "b")
+    out = torch.empty(n, a.shape[1] + b.shape[1], dtype=torch.float32, device=a.device)
+    check(load().dmn_merge_depths(ptr(aa), astride, a.shape[1], ptr(bb), bstride, b.shape[1], n, ptr(out),
+                                  current_stream()), "dmn_merge_depths")
+    return out

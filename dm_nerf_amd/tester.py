@@ -1,0 +1,64 @@
+"""Full-image rendering: the pose x chunk loop of the reference's ``render_test``
+(networks/tester.py:54-85).  The metric / image-writing half of that function (SSIM, LPIPS,
+Hungarian AP, PNG/JSON output, tester.py:87-168) is host-side evaluation and out of scope."""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+
+from .helpers import get_rays_k, z_val_sample
+from .render import dm_nerf
+
+
+def render_image(position_embedder, view_embedder, model_coarse, model_fine, c2w, hwk, args,
+                 chunk: Optional[int] = None, crop_mask=None, ray_range: Optional[Tuple[int, int]] = None):
+    """Render one pose.  ``chunk`` defaults to ``args.N_test`` (tester.py:62); the reference's
+    O(chunks^2) ``torch.cat`` growth (tester.py:72-76) is replaced by writes into preallocated
+    images.  ``ray_range=(a, b)`` renders only flat rays ``[a, b)`` (multi-GPU sharding of one
+    image) and returns flat ``[b-a, .]`` tensors."""
+    H, W, K = hwk
+    chunk = int(chunk or args.N_test)
+    rays_o, rays_d = get_rays_k(H, W, K, c2w)                                   # tester.py:58
+    rays_o = rays_o.reshape(-1, 3)
+    rays_d = rays_d.reshape(-1, 3)
+    lo, hi = (0, H * W) if ray_range is None else ray_range
+    n_total = hi - lo
+    rgb = torch.empty(n_total, 3, dtype=torch.float32, device=rays_o.device)
+    ins = torch.empty(n_total, model_fine.ins_num, dtype=torch.float32, device=rays_o.device)
+    with torch.no_grad():
+        for start in range(lo, hi, chunk):                                       # tester.py:62-71
+            n = min(chunk, hi - start)
+            z = z_val_sample(n, args.near, args.far, args.N_samples)
+            batch = torch.stack([rays_o[start:start + n], rays_d[start:start + n]], dim=0)
+            out = dm_nerf(batch, position_embedder, view_embedder, model_coarse, model_fine, z, args)
+            rgb[start - lo:start - lo + n] = out["rgb_fine"]
+            ins[start - lo:start - lo + n] = out["ins_fine"]
+    if ray_range is not None:
+        return rgb, ins
+    if crop_mask is not None:                                                    # tester.py:77-81
+        keep = torch.as_tensor(crop_mask).reshape(-1).to(rgb.device) == 1
+        rgb, ins = rgb[keep], ins[keep]
+        return (rgb.reshape(args.crop_height, args.crop_width, 3),
+                ins.reshape(args.crop_height, args.crop_width, ins.shape[-1]))
+    return rgb.reshape(H, W, 3), ins.reshape(H, W, ins.shape[-1])
+
+
+def render_test(position_embedder, view_embedder, model_coarse, model_fine, render_poses, hwk, args, gt_imgs=None,
+                gt_labels=None, ins_rgbs=None, savedir=None, matched_file=None, crop_mask=None, chunk=None):
+    """Reference signature (networks/tester.py:18-19).  Renders every pose and returns
+    ``(rgbs, inss, psnrs)``; PSNR against ``gt_imgs`` when given (tester.py:91).  The remaining
+    arguments are accepted for call compatibility and ignored (evaluation / file output)."""
+    rgbs: List[torch.Tensor] = []
+    inss: List[torch.Tensor] = []
+    psnrs: List[float] = []
+    for i, c2w in enumerate(render_poses):
+        rgb, ins = render_image(position_embedder, view_embedder, model_coarse, model_fine, c2w, hwk, args,
+                                chunk=chunk, crop_mask=crop_mask)
+        rgbs.append(rgb)
+        inss.append(ins)
+        if gt_imgs is not None:
+            gt = torch.as_tensor(gt_imgs[i]).to(rgb.device)
+            mse = torch.mean((rgb - gt) ** 2)
+            psnrs.append(float(-10.0 * torch.log10(mse)))
+    return rgbs, inss, psnrs

@@ -1,0 +1,107 @@
+/* dmnerf_hip.h -- C ABI of the MI355X-native (gfx950) DM-NeRF volumetric-render hot path.
+ *
+ * The reference (ChenLu-china/DM-NeRF) is pure Python; it has no FFI layer.  The drop-in
+ * boundary is therefore its Python function API.  This header is the
+ * C ABI beneath the Python shim `dm_nerf_amd`: plain pointers and sizes, no torch types.
+ * Each entry point names the reference interface (file:line under the reference root) whose
+ * computation it replaces.
+ *
+ * Conventions
+ *   - all device pointers are fp32 (or int32 where stated), dense, row-major, 16-byte aligned
+ *     allocations; `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - functions enqueue work on `stream` and return immediately; they never allocate device
+ *     memory and never synchronise (safe to capture in a hipGraph);
+ *   - return value: DMN_OK (0) or a negative DMN_ERR_* code; `dmn_error_string` explains it;
+ *   - `z` depth arrays take a ray stride: element (n, s) is z[n * z_ray_stride + s];
+ *     z_ray_stride = 0 means one depth lattice shared by all rays (the expanded view returned
+ *     by z_val_sample, networks/helpers.py:119).
+ */
+#ifndef DMNERF_HIP_H_
+#define DMNERF_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMN_OK 0
+#define DMN_ERR_BAD_ARG (-1)      /* null pointer, non-positive size, unsupported shape */
+#define DMN_ERR_UNSUPPORTED (-2)  /* e.g. ins_num + 1 > 128, S too large for the LDS path */
+#define DMN_ERR_LAUNCH (-3)       /* hipGetLastError() after a launch was not hipSuccess */
+#define DMN_ERR_NO_DEVICE (-4)
+
+int dmn_abi_version(void);
+const char* dmn_error_string(int code);
+/* Writes the name of device 0 (e.g. "gfx950:...") into buf; DMN_ERR_NO_DEVICE without a GPU. */
+int dmn_device_name(char* buf, int buf_len);
+
+/* ---- packed weights ---------------------------------------------------------------------
+ * One field network (DM_NeRF, networks/dm_nerf.py:58-106) = `dmn_field_param_floats(ins_num)`
+ * fp32 values in the reference's state_dict order (mlps.0.weight, mlps.0.bias, ...,
+ * rgb_linear.bias; config.py:146-159 builds two such networks).  `dmn_field_pack` gathers
+ * them into the kernel's blob (biases + MFMA-ordered weight stream, csrc/field_layout.h).    */
+int dmn_field_param_floats(int ins_num);
+long dmn_field_blob_floats(int ins_num);
+/* host: index_out[blob_floats] <- index into the flat parameter vector, or -1 (zero pad) */
+int dmn_field_pack_index(int ins_num, int32_t* index_out);
+/* device: blob[i] = index[i] < 0 ? 0 : params[index[i]] */
+int dmn_field_pack(const float* params, const int32_t* index, long blob_floats, float* blob, void* stream);
+
+/* ---- get_rays_k (networks/helpers.py:50-61) --------------------------------------------
+ * rays_o, rays_d: [H*W, 3].  K is passed as the five entries the reference reads
+ * (K[0][0], K[0][2], K[1][1], K[1][2], K[2][2], helpers.py:55) rounded to fp32, c2w as the
+ * 12 host floats of its top 3x4 block (helpers.py:58,60).                                   */
+int dmn_raygen(int H, int W, float k00, float k02, float k11, float k12, float k22, const float* c2w_3x4_host,
+               float* rays_o, float* rays_d, void* stream);
+
+/* ---- stratified jitter (networks/render.py:40-47) --------------------------------------- */
+int dmn_jitter_depths(const float* z, long z_ray_stride, const float* t_rand, long n_rays, int n_samples,
+                      float* z_out, void* stream);
+
+/* ---- Embedder.embed (networks/dm_nerf.py:37-38; bands :25) ------------------------------
+ * x: [M,3] -> out: [M, 3 + 6*n_freqs], ordering of dm_nerf.py:17-32.                         */
+int dmn_encode(const float* x, long n_points, int n_freqs, float* out, void* stream);
+
+/* ---- field evaluation: points -> encodings -> DM_NeRF.forward ----------------------------
+ * Replaces networks/render.py:37-38,49-61 (and :71-83 for the fine pass): viewdirs =
+ * d/|d|, pts = o + d*z, both encodings, and the whole network (networks/dm_nerf.py:80-106),
+ * fused in one kernel (fp32 MFMA).  raw: [n_rays * n_samples, 4 + ins_num + 1] laid out
+ * [rgb(3), sigma(1), ins(ins_num+1)] (dm_nerf.py:105).                                       */
+int dmn_field_fwd_rays(const float* rays_o, const float* rays_d, const float* z, long z_ray_stride, long n_rays,
+                       int n_samples, const float* blob, int ins_num, float* raw, void* stream);
+/* DM_NeRF.forward on caller-made encodings (networks/manipulator.py:125-131,
+ * tools/mesh_generator.py:41-45): embedded [M, 90] -> raw [M, 4 + ins_num + 1].              */
+int dmn_field_fwd_embedded(const float* embedded, long n_points, const float* blob, int ins_num, float* raw,
+                           void* stream);
+
+/* ---- render_train (networks/render.py:6-28) / manipulator_render (manipulator.py:86-105) --
+ * raw [N,S,C], z (stride), rays_d [N,3] -> rgb [N,3], weights [N,S], depth [N],
+ * ins [N, C-5] (keep_last = 0, render_train drops the last channel, render.py:26) or
+ * ins [N, C-4] (keep_last = 1, manipulator_render keeps it).  Any output pointer may be NULL. */
+int dmn_composite_fwd(const float* raw, const float* z, long z_ray_stride, const float* rays_d, long n_rays,
+                      int n_samples, int channels, int keep_last, float* rgb, float* weights, float* depth,
+                      float* ins, void* stream);
+
+/* ---- sample_pdf (networks/helpers.py:123-155) --------------------------------------------
+ * bins [N, n_bins] (row stride bins_ray_stride, 0 = shared), weights [N, n_bins-1] (row stride
+ * w_ray_stride, starting at `weights`), u: draw (n,k) = u[n * u_ray_stride + k] (stride 0 = one
+ * row shared by all rays, e.g. a torch.linspace(0,1,n_new) table for det=True), or NULL for
+ * det=True with the linspace evaluated in the kernel.  out: [N, n_new].                      */
+int dmn_sample_pdf(const float* bins, long bins_ray_stride, const float* weights, long w_ray_stride,
+                   const float* u, long u_ray_stride, long n_rays, int n_bins, int n_new, float* out, void* stream);
+
+/* ---- hierarchical resampling as called by dm_nerf (networks/render.py:66-70) --------------
+ * mids of z_coarse -> sample_pdf(mids, weights[:,1:-1], n_new, u as in dmn_sample_pdf) ->
+ * sort(cat([z_coarse, z_new])).  z_fine: [N, n_samples + n_new].  n_new may be 0.            */
+int dmn_resample_merge(const float* z_coarse, long z_ray_stride, const float* weights, const float* u,
+                       long u_ray_stride, long n_rays, int n_samples, int n_new, float* z_fine, void* stream);
+
+/* ---- torch.sort(torch.cat([a, b], -1)) on depth rows (render.py:70, manipulator.py:190-191) */
+int dmn_merge_depths(const float* a, long a_ray_stride, int n_a, const float* b, long b_ray_stride, int n_b,
+                     long n_rays, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMNERF_HIP_H_ */

@@ -43,6 +43,22 @@ def composite_bytes(n_rays: int, s: int, c: int) -> int:
     return n_rays * (s * c * 4 + s * 4 + 12 + s * 4 + 12 + 4 + 4 * (c - 5))
 
 
+def host_cores() -> int:
+    """CPU threads for the baseline leg: the process's share of the host (cgroup quota or affinity),
+    capped at 16 -- the CPU share of a 1-GPU box; os.cpu_count() reports all 256 host threads there
+    and oversubscribing them made the oracle 8x slower.  DMNERF_CPU_THREADS overrides."""
+    if os.environ.get("DMNERF_CPU_THREADS"):
+        return max(1, int(os.environ["DMNERF_CPU_THREADS"]))
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
 def synthetic_scene(device):
     """Weights and cameras of the synthetic 'study' workload.  The weight tensors come from the
     oracle module's seeded generator (data only, shared with the parity tests)."""
@@ -62,7 +78,7 @@ def cpu_baseline(K, pose, params, sample_rays: int, chunk: int):
     """The CPU oracle (port of the reference's PyTorch-CPU path) on a bounded sample of the same
     workload: the first `sample_rays` rays of the image in `chunk`-ray pieces, after one warm-up."""
     from oracle import dmnerf_cpu as oracle
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(host_cores())
     c2w = torch.from_numpy(pose)
     oracle.render_image(H, W, K, c2w, params[0], params[1], 4.0, 15.0, N_SAMPLES, N_IMPORTANCE, chunk=256,
                         max_rays=256)

@@ -138,9 +138,8 @@ def main():
     elapsed = time.perf_counter() - t0
     profile, ops.PROFILE = ops.PROFILE, None
     if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        from dm_nerf_amd.parallel import max_over_ranks
+        elapsed = max_over_ranks(elapsed, device)
 
     if rank != 0:
         if dist is not None:

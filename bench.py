@@ -35,6 +35,7 @@ N_SAMPLES, N_IMPORTANCE = 64, 128
 MACS_PER_POINT = 693_504                       # BASELINE.md section 3 (networks/dm_nerf.py:65-78)
 FLOP_PER_POINT = 2 * MACS_PER_POINT
 PEAK_F32_MFMA_TFLOPS = 157.3                   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_16BIT_MFMA_TFLOPS = 2500.0                # MI355X_MICROARCH.md: bf16 / f16 MFMA, dense (no sparsity)
 PEAK_HBM_GBS = 8000.0                          # MI355X_MICROARCH.md: HBM3E spec
 
 
@@ -96,6 +97,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--chunk", type=int, default=4096, help="rays per dm_nerf call (configs: N_test = 4096)")
     ap.add_argument("--cpu-rays", type=int, default=8192, help="rays of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--precision", default=os.environ.get("DMNERF_PRECISION", "fp16x3"),
+                    choices=["fp32", "fp16x3", "bf16x3"],
+                    help="field-kernel arithmetic: fp32 = exact fp32 MFMA; fp16x3 / bf16x3 = three 16-bit MFMAs "
+                         "per product (hi/lo split, fp32 accumulate)")
     ns = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -116,6 +121,7 @@ def main():
     dm.load_library()
     nerf, K, poses, params = synthetic_scene(device)
     pos, view, coarse, fine, args = nerf
+    args.precision = ns.precision
     pose = poses[rank % len(poses)]
     hwk = [H, W, K]
 
@@ -159,6 +165,11 @@ def main():
     n_f, t_f, pts_f = kernel_stats("field_fwd")
     n_c, t_c, pts_c = kernel_stats("composite")
     field_tflops = pts_f * FLOP_PER_POINT / t_f / 1e12
+    x3 = ns.precision != "fp32"
+    peak = PEAK_16BIT_MFMA_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS
+    kernel_name = (f"field_fwd_x3_kernel<{ns.precision}> (fused encodings + 8x256 field; every fp32 product = 3 "
+                   "16-bit MFMA products on hi/lo splits, fp32 accumulate)" if x3 else
+                   "field_fwd_kernel<1> (fused encodings + 8x256 field, fp32 MFMA)")
     c_ch = 5 + INS_NUM
     # composite launches alternate S=64 and S=192 with the same ray count; bytes by sample total
     comp_bytes = (pts_c // (N_SAMPLES + N_SAMPLES + N_IMPORTANCE)) * (
@@ -169,13 +180,16 @@ def main():
         "metric": "rays/sec, DM-SR study 800x800, 64+128 samples (PSNR vs reference path in `psnr_vs_cpu_oracle_db`)",
         "value": value, "unit": "rays/s", "n_gpus": world, "steps": ns.steps, "warmup": ns.warmup,
         "ms_per_step": elapsed / ns.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": {"fp32": "f32", "fp16x3": "f16x3 (hi/lo split, f32 accumulate)",
+                                       "bf16x3": "bf16x3 (hi/lo split, f32 accumulate)"}[ns.precision],
+        "data": "synthetic",
         "config": {"workload": "DM-SR 'study' 800x800, 64+128 hierarchical, 8x256 field, RGB+sigma+instance head "
                                "(ins_num=13), 1 image per GPU per step", "chunk_rays": ns.chunk,
-                   "parallelism": f"ray/image-sharded x{world}, no collective"},
-        "roofline": {"kernel": "field_fwd_kernel<1> (fused encodings + 8x256 field, fp32 MFMA)", "bound": "mfma",
-                     "achieved": field_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": field_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                   "precision": ns.precision, "parallelism": f"ray/image-sharded x{world}, no collective"},
+        "roofline": {"kernel": kernel_name, "bound": "mfma",
+                     "achieved": field_tflops, "peak": peak, "unit": "TFLOP/s",
+                     "frac": field_tflops / peak, "traffic": None,
+                     "mfma_flop_issued_per_algorithmic_flop": 3 if x3 else 1,
                      "launches": n_f, "avg_launch_ms": t_f / max(n_f, 1) * 1e3,
                      "algorithmic_flop_per_launch": pts_f * FLOP_PER_POINT / max(n_f, 1),
                      "time_share_of_step": t_f / elapsed},

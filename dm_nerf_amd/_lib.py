@@ -34,6 +34,12 @@ SIGNATURES = {
     "dmn_encode": (c_int, [_P, c_long, c_int, _P, _P]),
     "dmn_field_fwd_rays": (c_int, [_P, _P, _P, c_long, c_long, c_int, _P, c_int, _P, _P]),
     "dmn_field_fwd_embedded": (c_int, [_P, c_long, _P, c_int, _P, _P]),
+    "dmn_field_blob_x3_bytes": (c_long, [c_int]),
+    "dmn_field_pack_index_x3_len": (c_long, [c_int]),
+    "dmn_field_pack_index_x3": (c_int, [c_int, _P]),
+    "dmn_field_pack_x3": (c_int, [_P, _P, c_int, _P, _P]),
+    "dmn_field_fwd_rays_x3": (c_int, [_P, _P, _P, c_long, c_long, c_int, _P, c_int, c_int, _P, _P, _P]),
+    "dmn_field_fwd_embedded_x3": (c_int, [_P, c_long, _P, c_int, c_int, _P, _P, _P]),
     "dmn_composite_fwd": (c_int, [_P, _P, c_long, _P, c_long, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "dmn_sample_pdf": (c_int, [_P, c_long, _P, c_long, _P, c_long, c_long, c_int, c_int, _P, _P]),
     "dmn_resample_merge": (c_int, [_P, c_long, _P, _P, c_long, c_long, c_int, c_int, _P, _P]),

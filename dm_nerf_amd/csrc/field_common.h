@@ -1,0 +1,88 @@
+// Shared by the exact (fp32 MFMA) and the split-precision (3 x 16-bit MFMA) field kernels:
+// kernel arguments, LDS-DMA helper, and the per-lane prologue that turns a sample point into its
+// encoding registers (pts = o + d*z, viewdirs = d/|d|, sin/cos bands; networks/render.py:37-38,49-58,
+// networks/dm_nerf.py:17-32).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "field_layout.h"
+#include "trig.h"
+
+namespace dmn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct FieldArgs {
+  const float* rays_o;   // [N,3]   (rays mode)
+  const float* rays_d;   // [N,3]
+  const float* z;        // z[n*z_stride + s]
+  long z_stride;
+  const float* emb;      // [M,90]  (embedded mode; rays_* unused)
+  const void* blob;
+  float* raw;            // [M, C]
+  int* status;           // sticky flags (bit 0: fp16 range exceeded); may be null
+  long M;                // number of points
+  int S;                 // samples per ray (rays mode)
+  int ins_ch;            // ins_num + 1
+};
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  // LDS destination is wave-uniform base + lane*16 (hardware rule); g is per lane.
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// slots 2.. of an encoding register file: sin (half 0) / cos (half 1) of 2^f * coordinate
+template <int NF>
+__device__ __forceinline__ void encode_regs(float* e, float x, float y, float zc, int h) {
+  e[0] = h ? zc : x;
+  e[1] = h ? 0.f : y;
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    const float sc = (float)(1 << f);           // exact power of two: x*freq is exact (dm_nerf.py:25,31)
+    e[2 + 3 * f + 0] = trig_sel(x * sc, h);
+    e[2 + 3 * f + 1] = trig_sel(y * sc, h);
+    e[2 + 3 * f + 2] = trig_sel(zc * sc, h);
+  }
+}
+
+// Encoding registers of point mc for lane-half h: pe[32] (position, slots of pos_slot) and
+// qe[16] (view direction, slots of dir_slot).
+__device__ __forceinline__ void point_encodings(const FieldArgs& a, long mc, int h, float* pe, float* qe) {
+  if (a.emb != nullptr) {
+    const float* row = a.emb + mc * (kPosCh + kDirCh);
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const int s0 = pos_slot(j, 0), s1 = pos_slot(j, 1);
+      const int s = h ? s1 : s0;
+      pe[j] = s >= 0 ? row[s >= 0 ? s : 0] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int s0 = dir_slot(j, 0), s1 = dir_slot(j, 1);
+      const int s = h ? s1 : s0;
+      qe[j] = s >= 0 ? row[kPosCh + (s >= 0 ? s : 0)] : 0.f;
+    }
+  } else {
+    const long n = mc / a.S;
+    const int s = (int)(mc - n * a.S);
+    const float ox = a.rays_o[3 * n + 0], oy = a.rays_o[3 * n + 1], oz = a.rays_o[3 * n + 2];
+    const float dx = a.rays_d[3 * n + 0], dy = a.rays_d[3 * n + 1], dz = a.rays_d[3 * n + 2];
+    const float zv = a.z[n * a.z_stride + s];
+    // pts = rays_o + rays_d * z: separately rounded multiply and add, as torch does (render.py:49).
+    // The 2^9 band magnifies a 1-ulp difference in pts to ~5e-4 rad, so no fma contraction here.
+    const float px = __fadd_rn(ox, __fmul_rn(dx, zv));
+    const float py = __fadd_rn(oy, __fmul_rn(dy, zv));
+    const float pz = __fadd_rn(oz, __fmul_rn(dz, zv));
+    // viewdirs = rays_d / ||rays_d|| (render.py:37)
+    const float nrm = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+    const float vx = __fdiv_rn(dx, nrm), vy = __fdiv_rn(dy, nrm), vz = __fdiv_rn(dz, nrm);
+    encode_regs<kPosFreqs>(pe, px, py, pz, h);
+    encode_regs<kDirFreqs>(qe, vx, vy, vz, h);
+    qe[14] = 0.f;
+    qe[15] = 0.f;
+  }
+}
+
+}  // namespace dmn

@@ -18,38 +18,15 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/dmnerf_hip.h"
-#include "field_layout.h"
-#include "trig.h"
+#include "field_common.h"
 
 using namespace dmn;
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define DMN_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 namespace {
 
-struct FieldArgs {
-  const float* rays_o;   // [N,3]   (rays mode)
-  const float* rays_d;   // [N,3]
-  const float* z;        // z[n*z_stride + s]
-  long z_stride;
-  const float* emb;      // [M,90]  (embedded mode; rays_* unused)
-  const float* blob;
-  float* raw;            // [M, C]
-  long M;                // number of points
-  int S;                 // samples per ray (rays mode)
-  int ins_ch;            // ins_num + 1
-};
-
 constexpr int kLdsFloats = 2 * kStageFloats + kConstFloats;   // 80,896 B
-
-__device__ __forceinline__ void glds16(const float* g, float* l) {
-  // LDS destination is wave-uniform base + lane*16 (hardware rule); g is per lane.
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-}
 
 // each wave DMA-copies 8 of the stage's 32 chunks
 __device__ __forceinline__ void load_stage(const float* stream, int g, float* buf, int wave_s, int lane) {
@@ -66,20 +43,6 @@ __device__ __forceinline__ const float* stage_begin(const float* stream, int g, 
   __syncthreads();
   if (g + 1 < G) load_stage(stream, g + 1, lds + ((g + 1) & 1) * kStageFloats, wave_s, lane);
   return lds + (g & 1) * kStageFloats + lane * 4;
-}
-
-// slots 2.. of an encoding register file: sin (half 0) / cos (half 1) of 2^f * coordinate
-template <int NF>
-__device__ __forceinline__ void encode_regs(float* e, float x, float y, float zc, int h) {
-  e[0] = h ? zc : x;
-  e[1] = h ? 0.f : y;
-#pragma unroll
-  for (int f = 0; f < NF; ++f) {
-    const float sc = (float)(1 << f);           // exact power of two: x*freq is exact (dm_nerf.py:25,31)
-    e[2 + 3 * f + 0] = trig_sel(x * sc, h);
-    e[2 + 3 * f + 1] = trig_sel(y * sc, h);
-    e[2 + 3 * f + 2] = trig_sel(zc * sc, h);
-  }
 }
 
 __device__ __forceinline__ void bias_tiles8(f32x16* acc, const float* b) {
@@ -167,12 +130,13 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(const FieldArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, p = lane & 31, h = lane >> 5;
   const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const float* const stream = a.blob + kConstFloats;
+  const float* const blob = static_cast<const float*>(a.blob);
+  const float* const stream = blob + kConstFloats;
   constexpr int G = total_stages(T);
 
   // const section + stage 0 start streaming while the encodings are computed
   for (int c = wave_s; c < kConstChunks; c += 4)
-    glds16(a.blob + c * kChunkFloats + lane * 4, cst + c * kChunkFloats);
+    glds16(blob + c * kChunkFloats + lane * 4, cst + c * kChunkFloats);
   load_stage(stream, 0, lds, wave_s, lane);
 
   const long m = ((long)blockIdx.x * 4 + wave_s) * 32 + p;
@@ -180,39 +144,7 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(const FieldArgs a) {
   const long mc = valid ? m : a.M - 1;
 
   float pe[32], qe[16];
-  if (a.emb != nullptr) {
-    const float* row = a.emb + mc * (kPosCh + kDirCh);
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-      const int s0 = pos_slot(j, 0), s1 = pos_slot(j, 1);
-      const int s = h ? s1 : s0;
-      pe[j] = s >= 0 ? row[s >= 0 ? s : 0] : 0.f;
-    }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int s0 = dir_slot(j, 0), s1 = dir_slot(j, 1);
-      const int s = h ? s1 : s0;
-      qe[j] = s >= 0 ? row[kPosCh + (s >= 0 ? s : 0)] : 0.f;
-    }
-  } else {
-    const long n = mc / a.S;
-    const int s = (int)(mc - n * a.S);
-    const float ox = a.rays_o[3 * n + 0], oy = a.rays_o[3 * n + 1], oz = a.rays_o[3 * n + 2];
-    const float dx = a.rays_d[3 * n + 0], dy = a.rays_d[3 * n + 1], dz = a.rays_d[3 * n + 2];
-    const float zv = a.z[n * a.z_stride + s];
-    // pts = rays_o + rays_d * z: separately rounded multiply and add, as torch does (render.py:49).
-    // The 2^9 band magnifies a 1-ulp difference in pts to ~5e-4 rad, so no fma contraction here.
-    const float px = __fadd_rn(ox, __fmul_rn(dx, zv));
-    const float py = __fadd_rn(oy, __fmul_rn(dy, zv));
-    const float pz = __fadd_rn(oz, __fmul_rn(dz, zv));
-    // viewdirs = rays_d / ||rays_d|| (render.py:37)
-    const float nrm = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
-    const float vx = __fdiv_rn(dx, nrm), vy = __fdiv_rn(dy, nrm), vz = __fdiv_rn(dz, nrm);
-    encode_regs<kPosFreqs>(pe, px, py, pz, h);
-    encode_regs<kDirFreqs>(qe, vx, vy, vz, h);
-    qe[14] = 0.f;
-    qe[15] = 0.f;
-  }
+  point_encodings(a, mc, h, pe, qe);
 
   f32x16 acc[8];
   float act[128];
@@ -381,7 +313,8 @@ extern "C" int dmn_field_fwd_rays(const float* rays_o, const float* rays_d, cons
   if (n_rays == 0) return DMN_OK;
   if (!rays_o || !rays_d || !z || !blob || !raw) return DMN_ERR_BAD_ARG;
   if (ins_tiles(ins_num) > kMaxInsTiles) return DMN_ERR_UNSUPPORTED;
-  FieldArgs a{rays_o, rays_d, z, z_ray_stride, nullptr, blob, raw, n_rays * (long)n_samples, n_samples, ins_num + 1};
+  FieldArgs a{rays_o, rays_d, z, z_ray_stride, nullptr, blob, raw, nullptr, n_rays * (long)n_samples, n_samples,
+              ins_num + 1};
   return launch_field(a, ins_num, (hipStream_t)stream);
 }
 
@@ -391,6 +324,6 @@ extern "C" int dmn_field_fwd_embedded(const float* embedded, long n_points, cons
   if (n_points == 0) return DMN_OK;
   if (!embedded || !blob || !raw) return DMN_ERR_BAD_ARG;
   if (ins_tiles(ins_num) > kMaxInsTiles) return DMN_ERR_UNSUPPORTED;
-  FieldArgs a{nullptr, nullptr, nullptr, 0, embedded, blob, raw, n_points, 1, ins_num + 1};
+  FieldArgs a{nullptr, nullptr, nullptr, 0, embedded, blob, raw, nullptr, n_points, 1, ins_num + 1};
   return launch_field(a, ins_num, (hipStream_t)stream);
 }

@@ -1,0 +1,346 @@
+// Split-precision field kernel for gfx950: the same fused network as field_fwd.hip, with every
+// fp32 product W*X evaluated as  Whi*Xhi + Whi*Xlo + Wlo*Xhi  on v_mfma_f32_32x32x16_{f16,bf16}
+// (hi = 16-bit rounding of the value, lo = 16-bit rounding of the residual; fp32 accumulation).
+// Three 32-cycle MFMAs cover 16 k-values where the exact kernel needs eight 64-cycle ones: 5.3x the
+// MFMA throughput.  Measured accuracy against the fp32 reference path: fp16 split ~1e-6 relative on
+// the raw outputs (two 11-bit halves = 22 bits), bf16 split ~1e-5 (two 8-bit halves).  The fp16
+// flavour needs |activation| < 65504; the kernel tracks the running maximum and raises a sticky
+// status bit instead of returning silently wrong numbers (the host then re-renders exactly).
+//
+// Structure (differences from field_fwd.hip):
+//   * output tiles in the OUTER loop, k-steps inner: one 32x32 accumulator (plus one being
+//     converted) instead of eight, so the converted activations of the layer being produced
+//     (128 registers of packed hi/lo halves) and of the layer being consumed both fit;
+//   * the epilogue of tile t-1 (ReLU, hi/lo split, range tracking) is spread over the k-steps of
+//     tile t so its VALU work runs in the shadow of the MFMAs;
+//   * 64 KiB stages (32 k-step/tile pairs x [hi, lo] chunk), double buffered, A fragments prefetched
+//     two steps ahead inside a stage.
+#include <hip/hip_runtime.h>
+
+#include "../../include/dmnerf_hip.h"
+#include "field_common.h"
+
+using namespace dmn;
+
+namespace {
+
+struct PrecF16 {
+  typedef _Float16 elem;
+  typedef _Float16 frag __attribute__((ext_vector_type(8)));
+  static constexpr bool kCheckRange = true;
+  static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+struct PrecBF16 {
+  typedef __bf16 elem;
+  typedef __bf16 frag __attribute__((ext_vector_type(8)));
+  static constexpr bool kCheckRange = false;
+  static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+constexpr int kLdsBytes = 2 * kX3StageBytes + kConstFloats * 4;   // 146,432 B
+
+struct Ctx {
+  const char* stream;   // weight stream in global memory
+  char* lds;
+  const char* buf;      // this lane's read base inside the current stage
+  int g, G;             // next stage to begin, number of stages
+  int wave_s, lane;
+};
+
+// each wave DMA-copies 16 of the stage's 64 chunks
+__device__ __forceinline__ void load_stage(const Ctx& c, int g) {
+  const char* src = c.stream + (long)g * kX3StageBytes + (c.wave_s * 16) * 1024 + c.lane * 16;
+  char* dst = c.lds + (g & 1) * kX3StageBytes + (c.wave_s * 16) * 1024;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) glds16(src + q * 1024, dst + q * 1024);
+}
+
+// Barrier that retires stage g (its DMA has landed, every wave is done with stage g-1), then the
+// prefetch of stage g+1 into the other buffer.
+__device__ __forceinline__ void stage_begin(Ctx& c) {
+  __syncthreads();
+  if (c.g + 1 < c.G) load_stage(c, c.g + 1);
+  c.buf = c.lds + (c.g & 1) * kX3StageBytes + c.lane * 16;
+  ++c.g;
+}
+
+template <class P>
+__device__ __forceinline__ void split_pair(float x0, float x1, typename P::frag& hi, typename P::frag& lo, int j) {
+  typedef typename P::elem E;
+  const E h0 = (E)x0, h1 = (E)x1;
+  hi[j] = h0;
+  hi[j + 1] = h1;
+  lo[j] = (E)(x0 - (float)h0);
+  lo[j + 1] = (E)(x1 - (float)h1);
+}
+
+// ---- tile epilogues: piece q (0..7) handles accumulator registers 2q, 2q+1 of tile t -----------
+// -> next layer's operand fragments (register 16t + r is element (r & 7) of k-step 2t + (r >> 3))
+template <class P, bool RELU>
+struct EpiSplit {
+  typename P::frag* oh;
+  typename P::frag* ol;
+  float* amax;
+  float* sigma;          // density accumulation (only when dens)
+  const float* dw;       // density weights of this lane-half
+  bool dens;
+  __device__ __forceinline__ void operator()(int t, int q, const f32x16& acc) const {
+    float x0 = acc[2 * q], x1 = acc[2 * q + 1];
+    if (RELU) {
+      x0 = fmaxf(x0, 0.f);
+      x1 = fmaxf(x1, 0.f);
+    }
+    if (dens) *sigma = fmaf(x1, dw[16 * t + 2 * q + 1], fmaf(x0, dw[16 * t + 2 * q], *sigma));
+    if (P::kCheckRange) *amax = fmaxf(*amax, fmaxf(fabsf(x0), fabsf(x1)));
+    split_pair<P>(x0, x1, oh[2 * t + (q >> 2)], ol[2 * t + (q >> 2)], (2 * q) & 7);
+  }
+};
+// -> rgb_linear on the VALU (ReLU first; dm_nerf.py:91-93,102)
+struct EpiRgb {
+  float* rgb;            // [3] partial sums of this lane-half
+  const float* rw;       // cst + kConstRgbW + h*64
+  __device__ __forceinline__ void operator()(int t, int q, const f32x16& acc) const {
+    const float x0 = fmaxf(acc[2 * q], 0.f), x1 = fmaxf(acc[2 * q + 1], 0.f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      rgb[c] = fmaf(x1, rw[c * 128 + 16 * t + 2 * q + 1], fmaf(x0, rw[c * 128 + 16 * t + 2 * q], rgb[c]));
+  }
+};
+// -> instance logits straight to global memory (dm_nerf.py:103,105)
+struct EpiStore {
+  float* out;            // raw row of this lane's point, or null
+  int ins_ch, h;
+  __device__ __forceinline__ void operator()(int t, int q, const f32x16& acc) const {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int r = 2 * q + e;
+      const int ch = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (out != nullptr && ch < ins_ch) out[4 + ch] = acc[r];
+    }
+  }
+};
+
+// One layer: NT output tiles x (NKS + NKX) k-steps of 16; xh/xl: main operand fragments,
+// eh/el: extra fragments (position / direction encodings) appended to the k range.
+template <class P, int NT, int NKS, int NKX, class Epi>
+__device__ __forceinline__ void layer_x3(Ctx& c, const float* bias, const typename P::frag* xh,
+                                         const typename P::frag* xl, const typename P::frag* eh,
+                                         const typename P::frag* el, const Epi& epi) {
+  typedef typename P::frag frag;
+  constexpr int NK = NKS + NKX;
+  constexpr int STEPS = NT * NK;
+  constexpr int PPS = (8 + NK - 1) / NK;   // epilogue pieces per k-step
+  f32x16 acc[2];
+  frag ah[3], al[3];                       // A-fragment ring, indexed by step % 3
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {          // bias = initial accumulator
+      const f32x4 b = *reinterpret_cast<const f32x4*>(bias + t * 16 + v * 4);
+      acc[t & 1][4 * v + 0] = b.x; acc[t & 1][4 * v + 1] = b.y; acc[t & 1][4 * v + 2] = b.z; acc[t & 1][4 * v + 3] = b.w;
+    }
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+      const int step = t * NK + ks;
+      if ((step & 31) == 0) {              // 32 steps = 64 chunks = one stage
+        stage_begin(c);
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+          if (step + d < STEPS) {
+            ah[(step + d) % 3] = *reinterpret_cast<const frag*>(c.buf + ((2 * (step + d)) & 63) * 1024);
+            al[(step + d) % 3] = *reinterpret_cast<const frag*>(c.buf + ((2 * (step + d) + 1) & 63) * 1024);
+          }
+      }
+      if (step + 2 < STEPS && ((step + 2) >> 5) == (step >> 5)) {   // two steps ahead, same stage
+        ah[(step + 2) % 3] = *reinterpret_cast<const frag*>(c.buf + ((2 * (step + 2)) & 63) * 1024);
+        al[(step + 2) % 3] = *reinterpret_cast<const frag*>(c.buf + ((2 * (step + 2) + 1) & 63) * 1024);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above this step's MFMAs
+      if (t > 0) {
+#pragma unroll
+        for (int q = ks * PPS; q < (ks + 1) * PPS && q < 8; ++q) epi(t - 1, q, acc[(t - 1) & 1]);
+      }
+      const frag bh = ks < NKS ? xh[ks < NKS ? ks : 0] : eh[ks < NKS ? 0 : ks - NKS];
+      const frag bl = ks < NKS ? xl[ks < NKS ? ks : 0] : el[ks < NKS ? 0 : ks - NKS];
+      acc[t & 1] = P::mfma(ah[step % 3], bl, acc[t & 1]);
+      acc[t & 1] = P::mfma(al[step % 3], bh, acc[t & 1]);
+      acc[t & 1] = P::mfma(ah[step % 3], bh, acc[t & 1]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) epi(NT - 1, q, acc[(NT - 1) & 1]);
+}
+
+template <class P, int T>
+__global__ __launch_bounds__(256, 1) void field_fwd_x3_kernel(const FieldArgs a) {
+  typedef typename P::frag frag;
+  __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
+  float* const cst = reinterpret_cast<float*>(lds + 2 * kX3StageBytes);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, p = lane & 31, h = lane >> 5;
+  const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const char* const blob = static_cast<const char*>(a.blob);
+  Ctx c{blob + kConstFloats * 4, lds, nullptr, 0, kX3Stages, wave_s, lane};
+
+  for (int k = wave_s; k < kConstChunks; k += 4) glds16(blob + k * 1024 + lane * 16, lds + 2 * kX3StageBytes + k * 1024);
+  load_stage(c, 0);
+
+  const long m = ((long)blockIdx.x * 4 + wave_s) * 32 + p;
+  const bool valid = m < a.M;
+  const long mc = valid ? m : a.M - 1;
+  float amax = 0.f;
+  frag pe_h[4], pe_l[4], qe_h[2], qe_l[2];
+  {
+    float pe[32], qe[16];
+    point_encodings(a, mc, h, pe, qe);
+#pragma unroll
+    for (int j = 0; j < 32; j += 2) {
+      if (P::kCheckRange) amax = fmaxf(amax, fmaxf(fabsf(pe[j]), fabsf(pe[j + 1])));
+      split_pair<P>(pe[j], pe[j + 1], pe_h[j >> 3], pe_l[j >> 3], j & 7);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) split_pair<P>(qe[j], qe[j + 1], qe_h[j >> 3], qe_l[j >> 3], j & 7);
+  }
+
+  frag act_h[16], act_l[16], nxt_h[16], nxt_l[16];
+  float sigma = 0.f;
+  const float* const dw = cst + kConstDensW + h * 128;
+  typedef EpiSplit<P, true> Relu;
+  typedef EpiSplit<P, false> Lin;
+
+  // ---- mlps.0: position encoding (4 k-steps) -> act
+  layer_x3<P, 8, 4, 0>(c, cst + kConstBias8 + h * 128, pe_h, pe_l, pe_h, pe_l,
+                       Relu{act_h, act_l, &amax, &sigma, dw, false});
+  // ---- mlps.1 .. mlps.7 in ping-pong pairs; mlps.5 (skip connection) also consumes the position encoding
+  int l = 1;
+#pragma unroll 1
+  for (int it = 0; it < 3; ++it) {
+    layer_x3<P, 8, 16, 0>(c, cst + kConstBias8 + l * 256 + h * 128, act_h, act_l, pe_h, pe_l,
+                          Relu{nxt_h, nxt_l, &amax, &sigma, dw, false});
+    ++l;
+    layer_x3<P, 8, 16, 0>(c, cst + kConstBias8 + l * 256 + h * 128, nxt_h, nxt_l, pe_h, pe_l,
+                          Relu{act_h, act_l, &amax, &sigma, dw, l == kDepth - 1});   // density from mlps.7 output
+    ++l;
+    if (it == 1) {
+      layer_x3<P, 8, 16, 4>(c, cst + kConstBias8 + l * 256 + h * 128, act_h, act_l, pe_h, pe_l,
+                            Relu{nxt_h, nxt_l, &amax, &sigma, dw, false});
+      ++l;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        act_h[k] = nxt_h[k];
+        act_l[k] = nxt_l[k];
+      }
+    }
+  }
+  // ---- density_linear (dm_nerf.py:101): fp32 partial sums were taken while mlps.7 was converted
+  sigma += __shfl_xor(sigma, 32);
+  sigma += cst[kConstDensB];
+
+  // ---- rgb_feature_linear (no activation) -> nxt; rgb_feature_linears.0 on [feature, dirs] -> rgb_linear
+  layer_x3<P, 8, 16, 0>(c, cst + kConstBias8 + 8 * 256 + h * 128, act_h, act_l, pe_h, pe_l,
+                        Lin{nxt_h, nxt_l, &amax, &sigma, dw, false});
+  float rgb[3] = {0.f, 0.f, 0.f};
+  layer_x3<P, 4, 16, 2>(c, cst + kConstBias4 + h * 64, nxt_h, nxt_l, qe_h, qe_l, EpiRgb{rgb, cst + kConstRgbW + h * 64});
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    rgb[k] += __shfl_xor(rgb[k], 32);
+    rgb[k] += cst[kConstRgbB + k];
+  }
+  float* const out = valid ? a.raw + m * (4 + a.ins_ch) : nullptr;
+  if (out != nullptr && h == 0) {
+    out[0] = rgb[0];
+    out[1] = rgb[1];
+    out[2] = rgb[2];
+    out[3] = sigma;
+  }
+
+  // ---- ins_feature_linear on the trunk output (no activation) -> nxt; ins_feature_linears.0 (ReLU) -> act[0..7]
+  layer_x3<P, 8, 16, 0>(c, cst + kConstBias8 + 9 * 256 + h * 128, act_h, act_l, pe_h, pe_l,
+                        Lin{nxt_h, nxt_l, &amax, &sigma, dw, false});
+  layer_x3<P, 4, 16, 0>(c, cst + kConstBias4 + 128 + h * 64, nxt_h, nxt_l, pe_h, pe_l,
+                        Relu{act_h, act_l, &amax, &sigma, dw, false});
+  // ---- ins_linear: 128 -> ins_num + 1, T tiles, stored straight from the accumulators
+  layer_x3<P, T, 8, 0>(c, cst + kConstBiasO + h * 64, act_h, act_l, pe_h, pe_l, EpiStore{out, a.ins_ch, h});
+
+  if (P::kCheckRange && a.status != nullptr && !(amax < 60000.f)) atomicOr(a.status, DMN_STATUS_FP16_RANGE);
+}
+
+template <class P>
+int launch_x3(const FieldArgs& a, int ins_num, hipStream_t st) {
+  if (a.M <= 0) return DMN_OK;
+  const long blocks = (a.M + 127) / 128;
+  if (blocks > 0x7fffffffL) return DMN_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)blocks), block(256);
+  switch (ins_tiles(ins_num)) {
+    case 1: hipLaunchKernelGGL((field_fwd_x3_kernel<P, 1>), grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL((field_fwd_x3_kernel<P, 2>), grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL((field_fwd_x3_kernel<P, 3>), grid, block, 0, st, a); break;
+    case 4: hipLaunchKernelGGL((field_fwd_x3_kernel<P, 4>), grid, block, 0, st, a); break;
+    default: return DMN_ERR_UNSUPPORTED;
+  }
+  return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
+}
+
+int launch_prec(const FieldArgs& a, int ins_num, int precision, hipStream_t st) {
+  if (ins_num < 0 || ins_tiles(ins_num) > kMaxInsTiles) return DMN_ERR_UNSUPPORTED;
+  if (precision == DMN_PREC_FP16X3) return launch_x3<PrecF16>(a, ins_num, st);
+  if (precision == DMN_PREC_BF16X3) return launch_x3<PrecBF16>(a, ins_num, st);
+  return DMN_ERR_BAD_ARG;
+}
+
+// blob gather with the hi / lo split; entry i < kConstFloats is an fp32 constant, the rest are halves
+template <class E>
+__global__ void pack_x3_kernel(const float* __restrict__ params, const int32_t* __restrict__ index, char* __restrict__ blob) {
+  float* cst = reinterpret_cast<float*>(blob);
+  E* stream = reinterpret_cast<E*>(blob + kConstFloats * 4);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < kX3IndexLen; i += (long)gridDim.x * blockDim.x) {
+    const int32_t k = index[i];
+    const float v = k < 0 ? 0.f : params[k];
+    if (i < kConstFloats) {
+      cst[i] = v;
+    } else {
+      const long e = i - kConstFloats;
+      const bool lo = ((e / kX3ChunkHalfs) & 1) != 0;      // chunks alternate hi, lo
+      const E hi = (E)v;
+      stream[e] = lo ? (E)(v - (float)hi) : hi;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int dmn_field_pack_x3(const float* params, const int32_t* index, int precision, void* blob, void* stream) {
+  if (!params || !index || !blob) return DMN_ERR_BAD_ARG;
+  const dim3 grid(2048), block(256);
+  if (precision == DMN_PREC_FP16X3)
+    hipLaunchKernelGGL(pack_x3_kernel<_Float16>, grid, block, 0, (hipStream_t)stream, params, index, (char*)blob);
+  else if (precision == DMN_PREC_BF16X3)
+    hipLaunchKernelGGL(pack_x3_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, params, index, (char*)blob);
+  else
+    return DMN_ERR_BAD_ARG;
+  return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
+}
+
+extern "C" int dmn_field_fwd_rays_x3(const float* rays_o, const float* rays_d, const float* z, long z_ray_stride,
+                                     long n_rays, int n_samples, const void* blob, int ins_num, int precision,
+                                     float* raw, int* status, void* stream) {
+  if (n_rays < 0 || n_samples <= 0 || ins_num < 0 || z_ray_stride < 0) return DMN_ERR_BAD_ARG;
+  if (n_rays == 0) return DMN_OK;
+  if (!rays_o || !rays_d || !z || !blob || !raw) return DMN_ERR_BAD_ARG;
+  FieldArgs a{rays_o, rays_d, z, z_ray_stride, nullptr, blob, raw, status, n_rays * (long)n_samples, n_samples,
+              ins_num + 1};
+  return launch_prec(a, ins_num, precision, (hipStream_t)stream);
+}
+
+extern "C" int dmn_field_fwd_embedded_x3(const float* embedded, long n_points, const void* blob, int ins_num,
+                                         int precision, float* raw, int* status, void* stream) {
+  if (n_points < 0 || ins_num < 0) return DMN_ERR_BAD_ARG;
+  if (n_points == 0) return DMN_OK;
+  if (!embedded || !blob || !raw) return DMN_ERR_BAD_ARG;
+  FieldArgs a{nullptr, nullptr, nullptr, 0, embedded, blob, raw, status, n_points, 1, ins_num + 1};
+  return launch_prec(a, ins_num, precision, (hipStream_t)stream);
+}

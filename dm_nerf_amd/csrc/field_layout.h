@@ -130,4 +130,34 @@ DMN_HD constexpr int mlp_stage(int l) {
   return l == 0 ? kStageL0 : (l <= 4 ? kStageL1 + 8 * (l - 1) : (l == 5 ? kStageL5 : kStageL6 + 8 * (l - 6)));
 }
 
+// =====================================================================================
+// Split-precision ("x3") blob: same const section (fp32), weight stream in 16-bit hi / lo halves
+// for the 3-MFMA product  W*X ~= Whi*Xhi + Whi*Xlo + Wlo*Xhi  on v_mfma_f32_32x32x16_{f16,bf16}.
+//
+// A k-step now covers 16 input features: element j (0..7) of lane-half h in k-step ks is activation
+// register 8*ks + j, i.e. feature feat_of(8*ks + j, h) (same map as above, see field_fwd_x3.hip).
+// The kernel walks output tiles in the OUTER loop: for tile t, for k-step ks: [hi chunk, lo chunk];
+// chunk[lane][j] = W[32*t + (lane&31)][col(8*ks + j, lane>>5)], 64 lanes x 8 halves = 1 KiB.
+// 64 chunks = one 64 KiB stage; every layer is padded to whole stages.
+// =====================================================================================
+constexpr int kX3ChunkHalfs = 512;
+constexpr int kX3StageChunks = 64;
+constexpr int kX3StageBytes = kX3StageChunks * 1024;
+constexpr int kX3StageL0 = 0;      // 8 tiles x 4 k-steps            ->  64 chunks, 1 stage
+constexpr int kX3StageL1 = 1;      // mlps.1..4: 8 x 16 -> 256 chunks, 4 stages each
+constexpr int kX3StageL5 = 17;     // 8 x (16 + 4) -> 320 chunks, 5 stages
+constexpr int kX3StageL6 = 22;     // mlps.6, mlps.7
+constexpr int kX3StageRgbF = 30;
+constexpr int kX3StageRgbH = 34;   // 4 x (16 + 2) -> 144 chunks, 3 stages (padded)
+constexpr int kX3StageInsF = 37;
+constexpr int kX3StageInsH = 41;   // 4 x 16 -> 128 chunks, 2 stages
+constexpr int kX3StageInsO = 43;   // T x 8 -> 16 T chunks, 1 stage
+constexpr int kX3Stages = 44;
+DMN_HD constexpr int x3_mlp_stage(int l) {
+  return l == 0 ? kX3StageL0 : (l <= 4 ? kX3StageL1 + 4 * (l - 1) : (l == 5 ? kX3StageL5 : kX3StageL6 + 4 * (l - 6)));
+}
+constexpr long kX3StreamHalfs = (long)kX3Stages * kX3StageChunks * kX3ChunkHalfs;
+constexpr long kX3BlobBytes = (long)kConstFloats * 4 + kX3StreamHalfs * 2;
+constexpr long kX3IndexLen = (long)kConstFloats + kX3StreamHalfs;   // one gather entry per float / half
+
 }  // namespace dmn

@@ -75,28 +75,34 @@ class DM_NeRF(nn.Module):
         self.density_linear = nn.Linear(W, 1)
         self.ins_linear = nn.Linear(W // 2, ins_num + 1)
         self.rgb_linear = nn.Linear(W // 2, 3)
-        self._blob: Optional[torch.Tensor] = None
-        self._blob_key: Optional[Tuple] = None
-        self._index: Optional[torch.Tensor] = None
+        self.precision = "fp32"          # arithmetic of forward(); the render path passes its own
+        self._blobs = {}                 # precision -> (key, blob)
+        self._indices = {}               # (flavour, device) -> gather table
 
     # ---- packed weights -------------------------------------------------------------------
     def _ordered_params(self) -> List[torch.Tensor]:
         return [p for _, p in self.named_parameters()]      # registration order = state_dict order
 
-    def blob(self) -> torch.Tensor:
-        """Device blob consumed by the field kernel; re-gathered only when a parameter changed
-        (optimizer steps and load_state_dict bump the tensors' version counters)."""
+    def blob(self, precision: str = "fp32") -> torch.Tensor:
+        """Device blob consumed by the field kernel of the given precision; re-gathered only when a
+        parameter changed (optimizer steps and load_state_dict bump the tensors' version counters)."""
+        ops.precision_code(precision)
         params = self._ordered_params()
         dev = params[0].device
         key = (dev, tuple((p.data_ptr(), p._version) for p in params))
-        if self._blob is None or self._blob_key != key:
-            if self._index is None or self._index.device != dev:
-                self._index = ops.pack_index(self.ins_num, dev)
-            with torch.no_grad():
-                flat = torch.cat([p.detach().reshape(-1).float() for p in params])
-            self._blob = ops.pack_blob(flat, self._index)
-            self._blob_key = key
-        return self._blob
+        cached = self._blobs.get(precision)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        flavour = "fp32" if precision == "fp32" else "x3"
+        index = self._indices.get((flavour, dev))
+        if index is None:
+            index = ops.pack_index(self.ins_num, dev) if flavour == "fp32" else ops.pack_index_x3(self.ins_num, dev)
+            self._indices[(flavour, dev)] = index
+        with torch.no_grad():
+            flat = torch.cat([p.detach().reshape(-1).float() for p in params])
+        blob = ops.pack_blob(flat, index) if flavour == "fp32" else ops.pack_blob_x3(flat, index, self.ins_num, precision)
+        self._blobs[precision] = (key, blob)
+        return blob
 
     def _refuse_grad(self):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
@@ -106,4 +112,4 @@ class DM_NeRF(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         self._refuse_grad()
-        return ops.field_embedded(x, self.blob(), self.ins_num)
+        return ops.field_embedded(x, self.blob(self.precision), self.ins_num, self.precision)

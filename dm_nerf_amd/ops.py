@@ -14,6 +14,35 @@ from ._lib import check, current_stream, load, ptr
 
 MAX_INS_CHANNELS = 128
 
+# arithmetic of the field kernel (include/dmnerf_hip.h DMN_PREC_*)
+PRECISIONS = {"fp32": 0, "fp16x3": 1, "bf16x3": 2}
+STATUS_FP16_RANGE = 1
+_status = {}
+
+
+def precision_code(precision: str) -> int:
+    try:
+        return PRECISIONS[precision]
+    except KeyError:
+        raise ValueError(f"precision must be one of {sorted(PRECISIONS)}, got {precision!r}") from None
+
+
+def status_word(device) -> torch.Tensor:
+    """Per-device sticky status int the split-precision kernels OR flags into."""
+    key = torch.device(device).index
+    if key not in _status:
+        _status[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _status[key]
+
+
+def take_status(device) -> int:
+    """Read and clear the status word (synchronises with the device)."""
+    w = status_word(device)
+    v = int(w.item())
+    if v:
+        w.zero_()
+    return v
+
 # Optional per-launch timing hook (bench.py): when set to a list, every field / composite launch
 # appends (kernel_name, start_event, end_event, work_items) with HIP events recorded on the launch
 # stream.  None (the default) adds nothing to the launch path.
@@ -93,6 +122,25 @@ def pack_blob(flat_params: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
     return blob
 
 
+def pack_index_x3(ins_num: int, device) -> torch.Tensor:
+    lib = load()
+    n = lib.dmn_field_pack_index_x3_len(ins_num)
+    if n < 0:
+        raise ValueError(f"ins_num={ins_num} unsupported (ins_num + 1 must be <= {MAX_INS_CHANNELS})")
+    idx = np.empty(n, dtype=np.int32)
+    check(lib.dmn_field_pack_index_x3(ins_num, idx.ctypes.data), "dmn_field_pack_index_x3")
+    return torch.from_numpy(idx).to(device)
+
+
+def pack_blob_x3(flat_params: torch.Tensor, index: torch.Tensor, ins_num: int, precision: str) -> torch.Tensor:
+    _dev(flat_params, "flat_params")
+    n_bytes = load().dmn_field_blob_x3_bytes(ins_num)
+    blob = torch.empty(n_bytes, dtype=torch.uint8, device=flat_params.device)
+    check(load().dmn_field_pack_x3(ptr(flat_params), ptr(index), precision_code(precision), ptr(blob),
+                                   current_stream()), "dmn_field_pack_x3")
+    return blob
+
+
 def raygen(H: int, W: int, K, c2w) -> Tuple[torch.Tensor, torch.Tensor]:
     """get_rays_k; K: 3x3/4x4 array-like (host), c2w: 3x4/4x4 (host array or tensor)."""
     K = np.asarray(K, dtype=np.float64)
@@ -128,7 +176,7 @@ def encode(x: torch.Tensor, n_freqs: int) -> torch.Tensor:
 
 
 def field_rays(rays_o: torch.Tensor, rays_d: torch.Tensor, z: torch.Tensor, blob: torch.Tensor,
-               ins_num: int) -> torch.Tensor:
+               ins_num: int, precision: str = "fp32") -> torch.Tensor:
     n = rays_o.shape[0]
     rays_o = _dev(rays_o, "rays_o").contiguous()
     rays_d = _dev(rays_d, "rays_d").contiguous()
@@ -136,19 +184,29 @@ def field_rays(rays_o: torch.Tensor, rays_d: torch.Tensor, z: torch.Tensor, blob
     s = z.shape[1]
     raw = torch.empty(n, s, 5 + ins_num, dtype=torch.float32, device=rays_o.device)
     with _timed("field_fwd", n * s):
-        check(load().dmn_field_fwd_rays(ptr(rays_o), ptr(rays_d), ptr(zz), stride, n, s, ptr(blob), ins_num,
-                                        ptr(raw), current_stream()), "dmn_field_fwd_rays")
+        if precision == "fp32":
+            check(load().dmn_field_fwd_rays(ptr(rays_o), ptr(rays_d), ptr(zz), stride, n, s, ptr(blob), ins_num,
+                                            ptr(raw), current_stream()), "dmn_field_fwd_rays")
+        else:
+            check(load().dmn_field_fwd_rays_x3(ptr(rays_o), ptr(rays_d), ptr(zz), stride, n, s, ptr(blob), ins_num,
+                                               precision_code(precision), ptr(raw), ptr(status_word(raw.device)),
+                                               current_stream()), "dmn_field_fwd_rays_x3")
     return raw
 
 
-def field_embedded(embedded: torch.Tensor, blob: torch.Tensor, ins_num: int) -> torch.Tensor:
+def field_embedded(embedded: torch.Tensor, blob: torch.Tensor, ins_num: int, precision: str = "fp32") -> torch.Tensor:
     _dev(embedded, "embedded")
     if embedded.shape[-1] != 90:
         raise ValueError(f"embedded input must have 63+27 channels, got {embedded.shape[-1]}")
     flat = embedded.reshape(-1, 90).contiguous()
     raw = torch.empty(flat.shape[0], 5 + ins_num, dtype=torch.float32, device=embedded.device)
-    check(load().dmn_field_fwd_embedded(ptr(flat), flat.shape[0], ptr(blob), ins_num, ptr(raw), current_stream()),
-          "dmn_field_fwd_embedded")
+    if precision == "fp32":
+        check(load().dmn_field_fwd_embedded(ptr(flat), flat.shape[0], ptr(blob), ins_num, ptr(raw),
+                                            current_stream()), "dmn_field_fwd_embedded")
+    else:
+        check(load().dmn_field_fwd_embedded_x3(ptr(flat), flat.shape[0], ptr(blob), ins_num,
+                                               precision_code(precision), ptr(raw), ptr(status_word(raw.device)),
+                                               current_stream()), "dmn_field_fwd_embedded_x3")
     return raw.reshape(*embedded.shape[:-1], raw.shape[-1])
 
 

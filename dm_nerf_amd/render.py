@@ -35,13 +35,18 @@ def dm_nerf(rays, position_embedder, view_embedder, model_coarse, model_fine, z_
 
     ``args`` supplies ``perturb``, ``N_importance``, ``is_train`` and ``N_ins`` like the reference's
     namespace; optional ``args.t_rand`` / ``args.u`` replace the two ``torch.rand`` draws of the
-    stochastic path (render.py:46, helpers.py:135) so that it can be checked against recorded draws."""
+    stochastic path (render.py:46, helpers.py:135) so that it can be checked against recorded draws.
+    ``args.precision`` selects the field kernel's arithmetic: "fp32" (default: exact fp32 MFMA), "fp16x3"
+    or "bf16x3" (three 16-bit MFMAs per product).  With "fp16x3" the caller must look at
+    ``ops.take_status`` afterwards (``render_image`` does): activations beyond the fp16 range are flagged,
+    never silently wrong."""
     _check_embedders(position_embedder, view_embedder)
     if not (isinstance(model_coarse, DM_NeRF) and isinstance(model_fine, DM_NeRF)):
         raise TypeError("model_coarse / model_fine must be dm_nerf_amd.DM_NeRF modules")
     model_coarse._refuse_grad()
     model_fine._refuse_grad()
     rays_o, rays_d = rays
+    precision = getattr(args, "precision", None) or "fp32"
     n_importance = int(args.N_importance)
     perturb = float(args.perturb)
 
@@ -51,7 +56,8 @@ def dm_nerf(rays, position_embedder, view_embedder, model_coarse, model_fine, z_
             t_rand = torch.rand(z_vals_coarse.shape, device=rays_d.device)
         z_vals_coarse = ops.jitter_depths(z_vals_coarse, t_rand)                       # render.py:40-47
 
-    raw_coarse = ops.field_rays(rays_o, rays_d, z_vals_coarse, model_coarse.blob(), model_coarse.ins_num)
+    raw_coarse = ops.field_rays(rays_o, rays_d, z_vals_coarse, model_coarse.blob(precision), model_coarse.ins_num,
+                                precision)
     rgb_coarse, weights_coarse, depth_coarse, ins_coarse = ops.composite(raw_coarse, z_vals_coarse, rays_d)
 
     if n_importance > 0:
@@ -65,7 +71,7 @@ def dm_nerf(rays, position_embedder, view_embedder, model_coarse, model_fine, z_
         u = None
     z_vals_fine = ops.resample_merge(z_vals_coarse, weights_coarse, n_importance, u)    # render.py:66-70
 
-    raw_fine = ops.field_rays(rays_o, rays_d, z_vals_fine, model_fine.blob(), model_fine.ins_num)
+    raw_fine = ops.field_rays(rays_o, rays_d, z_vals_fine, model_fine.blob(precision), model_fine.ins_num, precision)
     rgb_fine, _, depth_fine, ins_fine = ops.composite(raw_fine, z_vals_fine, rays_d)
 
     if args.is_train and getattr(args, "N_ins", None) is not None:                      # render.py:88-90

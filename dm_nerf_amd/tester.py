@@ -7,6 +7,10 @@ from typing import List, Optional, Tuple
 
 import torch
 
+import warnings
+from types import SimpleNamespace
+
+from . import ops
 from .helpers import get_rays_k, z_val_sample
 from .render import dm_nerf
 
@@ -19,6 +23,9 @@ def render_image(position_embedder, view_embedder, model_coarse, model_fine, c2w
     image) and returns flat ``[b-a, .]`` tensors."""
     H, W, K = hwk
     chunk = int(chunk or args.N_test)
+    precision = getattr(args, "precision", None) or "fp32"
+    if precision == "fp16x3":
+        ops.take_status(torch.device("cuda", torch.cuda.current_device()))      # clear stale flags
     rays_o, rays_d = get_rays_k(H, W, K, c2w)                                   # tester.py:58
     rays_o = rays_o.reshape(-1, 3)
     rays_d = rays_d.reshape(-1, 3)
@@ -34,6 +41,12 @@ def render_image(position_embedder, view_embedder, model_coarse, model_fine, c2w
             out = dm_nerf(batch, position_embedder, view_embedder, model_coarse, model_fine, z, args)
             rgb[start - lo:start - lo + n] = out["rgb_fine"]
             ins[start - lo:start - lo + n] = out["ins_fine"]
+    if precision == "fp16x3" and ops.take_status(rgb.device) & ops.STATUS_FP16_RANGE:
+        # an activation left the fp16 range somewhere in this image: redo it with exact fp32 products
+        warnings.warn("dm_nerf_amd: fp16x3 range exceeded, re-rendering this image with precision='fp32'")
+        exact = SimpleNamespace(**{**vars(args), "precision": "fp32"})
+        return render_image(position_embedder, view_embedder, model_coarse, model_fine, c2w, hwk, exact,
+                            chunk=chunk, crop_mask=crop_mask, ray_range=ray_range)
     if ray_range is not None:
         return rgb, ins
     if crop_mask is not None:                                                    # tester.py:77-81

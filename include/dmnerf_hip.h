@@ -31,6 +31,13 @@ extern "C" {
 #define DMN_ERR_LAUNCH (-3)       /* hipGetLastError() after a launch was not hipSuccess */
 #define DMN_ERR_NO_DEVICE (-4)
 
+/* arithmetic of the field kernel */
+#define DMN_PREC_FP32 0    /* v_mfma_f32_32x32x2_f32: exact fp32 products (parity mode) */
+#define DMN_PREC_FP16X3 1  /* 3 x v_mfma_f32_32x32x16_f16 per product on hi/lo fp16 splits (~1e-6 rel.) */
+#define DMN_PREC_BF16X3 2  /* 3 x v_mfma_f32_32x32x16_bf16 per product on hi/lo bf16 splits (~1e-5 rel.) */
+/* bits of the sticky status word the split-precision kernels OR into */
+#define DMN_STATUS_FP16_RANGE 1  /* an activation left the fp16 range: re-run with another precision */
+
 int dmn_abi_version(void);
 const char* dmn_error_string(int code);
 /* Writes the name of device 0 (e.g. "gfx950:...") into buf; DMN_ERR_NO_DEVICE without a GPU. */
@@ -74,6 +81,19 @@ int dmn_field_fwd_rays(const float* rays_o, const float* rays_d, const float* z,
  * tools/mesh_generator.py:41-45): embedded [M, 90] -> raw [M, 4 + ins_num + 1].              */
 int dmn_field_fwd_embedded(const float* embedded, long n_points, const float* blob, int ins_num, float* raw,
                            void* stream);
+
+/* Split-precision flavours of the two calls above (same reference lines, same outputs).  `blob` is
+ * the x3 blob (dmn_field_blob_x3_bytes / dmn_field_pack_index_x3 / dmn_field_pack_x3, made for the same
+ * `precision`), `status` an optional device int the kernel ORs DMN_STATUS_* bits into.               */
+long dmn_field_blob_x3_bytes(int ins_num);
+long dmn_field_pack_index_x3_len(int ins_num);
+int dmn_field_pack_index_x3(int ins_num, int32_t* index_out);
+int dmn_field_pack_x3(const float* params, const int32_t* index, int precision, void* blob, void* stream);
+int dmn_field_fwd_rays_x3(const float* rays_o, const float* rays_d, const float* z, long z_ray_stride, long n_rays,
+                          int n_samples, const void* blob, int ins_num, int precision, float* raw, int* status,
+                          void* stream);
+int dmn_field_fwd_embedded_x3(const float* embedded, long n_points, const void* blob, int ins_num, int precision,
+                              float* raw, int* status, void* stream);
 
 /* ---- render_train (networks/render.py:6-28) / manipulator_render (manipulator.py:86-105) --
  * raw [N,S,C], z (stride), rays_d [N,3] -> rgb [N,3], weights [N,S], depth [N],

@@ -381,6 +381,74 @@ def test_replica_shape_config():
     assert rel_err(H(got["rgb_coarse"]), want["rgb_coarse"].numpy()) < 1e-4
 
 
+# ---- split-precision field kernels (3 x 16-bit MFMA per product) -------------------------------------
+@pytest.mark.parametrize("precision,tol", [("fp16x3", 2e-5), ("bf16x3", 1e-4)])
+@pytest.mark.parametrize("ins_num,seed", [(13, 0), (93, 3), (7, 4)])
+def test_split_precision_field_matches_reference_golden(golden, precision, tol, ins_num, seed):
+    g = golden("g3_field.npz")
+    x, v = cases.field_rows()
+    emb = torch.cat([oracle.encode(torch.from_numpy(x), 10), oracle.encode(torch.from_numpy(v), 4)], -1)
+    model = dm.DM_NeRF(8, 256, 63, 27, [4], ins_num).to(DEV)
+    model.load_state_dict(oracle.make_params(ins_num, seed))
+    model.precision = precision
+    ops.take_status(DEV)
+    with torch.no_grad():
+        raw = H(model(emb.to(DEV)))
+    err = rel_err(raw, g[f"raw_ins{ins_num}"])
+    print(f"{precision} ins_num={ins_num}: rel err {err:.2e}")
+    assert err < tol
+    assert ops.take_status(DEV) == 0
+
+
+@pytest.mark.parametrize("precision", ["fp16x3", "bf16x3"])
+def test_split_precision_on_rays_and_whole_call(golden, precision):
+    g = golden("g6_path.npz")
+    n = 128
+    o, d, _, _ = cases.path_rays(n)
+    pos, view, coarse, fine, args = nets(13, 0, 1)
+    args.precision = precision
+    rays = G(np.stack([o, d], 0))
+    z = dm.z_val_sample(n, cases.NEAR, cases.FAR, cases.N_SAMPLES)
+    with torch.no_grad():
+        out = dm.dm_nerf(rays, pos, view, coarse, fine, z, args)
+    _check_path(out, g, "det")
+    assert rel_err(H(out["raw_coarse"][:8]), g["det_raw_coarse_head"]) < 1e-4
+    # fine stage on the reference's depths: 1e-4 outright
+    z_fine = G(g["det_z_vals_fine"])
+    raw = ops.field_rays(G(o), G(d), z_fine, fine.blob(precision), 13, precision)
+    rgb, w, depth, ins = dm.render_train(raw, z_fine, G(d))
+    for got, key in ((raw[:8], "det_raw_fine_head"), (rgb, "det_rgb_fine"), (depth, "det_depth_fine"),
+                     (ins, "det_ins_fine")):
+        assert rel_err(H(got), g[key]) < 1e-4, key
+    # ragged tile tail and odd sample count
+    params = oracle.make_params(13, 1)
+    zz = G(g["det_z_vals_fine"][:5, :101])
+    raw = H(ops.field_rays(G(o[:5]), G(d[:5]), zz, fine.blob(precision), 13, precision))
+    with torch.no_grad():
+        want = oracle.field_on_rays(params, torch.from_numpy(o[:5]), torch.from_numpy(d[:5]), zz.cpu()).numpy()
+    assert rel_err(raw, want) < 1e-4
+
+
+def test_fp16_range_flag_and_exact_fallback():
+    """Activations beyond the fp16 range must be flagged and the image re-rendered exactly."""
+    pos, view, coarse, fine, args = nets(13, 0, 1)
+    big = oracle.make_params(13, 0)
+    big["mlps.0.weight"] = big["mlps.0.weight"] * 3e4          # trunk activations ~1e5 > 65504
+    coarse.load_state_dict(big)
+    Hh, W = 8, 8
+    hwk = [Hh, W, cases.study_intrinsics(Hh, W)]
+    args.precision = "fp32"
+    exact_rgb, exact_ins = dm.render_image(pos, view, coarse, fine, cases.study_c2w(), hwk, args)
+    args.precision = "fp16x3"
+    with pytest.warns(UserWarning, match="fp16x3 range exceeded"):
+        rgb, ins = dm.render_image(pos, view, coarse, fine, cases.study_c2w(), hwk, args)
+    np.testing.assert_array_equal(H(rgb), H(exact_rgb))
+    np.testing.assert_array_equal(H(ins), H(exact_ins))
+    args.precision = "bf16x3"                                   # bf16 has fp32's range: no flag, close result
+    rgb_b, _ = dm.render_image(pos, view, coarse, fine, cases.study_c2w(), hwk, args)
+    assert np.isfinite(H(rgb_b)).all()
+
+
 # ---- error behaviour ------------------------------------------------------------------------------
 def test_errors_are_python_exceptions():
     pos, view, coarse, fine, args = nets(13, 0, 1)

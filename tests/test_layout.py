@@ -203,3 +203,123 @@ def test_layout_rejects_unsupported_instance_counts():
     assert lib.dmn_field_blob_floats(128) < 0          # ins_num + 1 = 129 > 128
     assert lib.dmn_field_blob_floats(127) > 0
     assert lib.dmn_field_param_floats(-1) < 0
+
+
+# ---------------------------------------------------------------------------------------------
+# split-precision ("x3") blob: lane-exact model of v_mfma_f32_32x32x16_{f16,bf16} operand maps
+# (A: lane l holds A[l&31][8*(l>>5) + j], B: B[8*(l>>5) + j][l&31], j = 0..7), tiles in the outer loop
+# ---------------------------------------------------------------------------------------------
+X3_STAGE = {"l0": 0, "l1": 1, "l5": 17, "l6": 22, "rgbf": 30, "rgbh": 34, "insf": 37, "insh": 41, "inso": 43}
+X3_CHUNK = 512
+
+
+class WaveX3:
+    def __init__(self, cst, stream):
+        self.cst, self.stream = cst, stream
+
+    def layer(self, stage0, n_tiles, frags, bias_off):
+        """frags: list of k-step operand fragments [8][64] (element j, lane).  Returns tiles [n_tiles][32][32]."""
+        nk = len(frags)
+        acc = np.zeros((n_tiles, 32, 32))
+        for t in range(n_tiles):
+            for i in range(16):
+                for h in range(2):
+                    acc[t, (i & 3) + 8 * (i >> 2) + 4 * h, :] = self.cst[bias_off + h * 16 * n_tiles + 16 * t + i]
+            for ks in range(nk):
+                chunk = stage0 * 64 + (t * nk + ks) * 2          # hi chunk (the lo chunk is zero in this model)
+                a = self.stream[chunk * X3_CHUNK:(chunk + 1) * X3_CHUNK].reshape(64, 8)
+                A = np.zeros((32, 16)); B = np.zeros((16, 32))
+                for j in range(8):
+                    A[P, 8 * HALF + j] = a[:, j]
+                    B[8 * HALF + j, P] = frags[ks][j]
+                acc[t] += A @ B
+        return acc
+
+    @staticmethod
+    def frags_of(acc, relu):
+        """accumulator tiles -> operand fragments of the next layer: register 16t + r = element r & 7 of k-step 2t + (r >> 3)."""
+        regs = Wave.regs(acc)
+        if relu:
+            regs = np.maximum(regs, 0)
+        return [regs[8 * ks:8 * ks + 8] for ks in range(regs.shape[0] // 8)], regs
+
+
+def simulate_x3(idx, flat, emb, ins_num):
+    T = (ins_num + 1 + 31) // 32
+    vals = np.where(idx >= 0, flat[np.clip(idx, 0, None)], 0.0).astype(np.float64)
+    cst, stream = vals[:CONST], vals[CONST:].copy()
+    chunk_id = np.arange(stream.size) // X3_CHUNK
+    stream[chunk_id % 2 == 1] = 0.0                               # lo chunks carry residuals: zero in exact arithmetic
+    w = WaveX3(cst, stream)
+    pe = np.zeros((32, 64)); qe = np.zeros((16, 64))
+    for j in range(32):
+        for h in range(2):
+            s = pos_slot(j, h)
+            if s >= 0:
+                pe[j, HALF == h] = emb[:, s]
+    for j in range(16):
+        for h in range(2):
+            s = pos_slot(j, h, n_freq_slots=12)
+            if s >= 0:
+                qe[j, HALF == h] = emb[:, 63 + s]
+    pe_f = [pe[8 * k:8 * k + 8] for k in range(4)]
+    qe_f = [qe[8 * k:8 * k + 8] for k in range(2)]
+    act, _ = w.frags_of(w.layer(X3_STAGE["l0"], 8, pe_f, C_BIAS8), True)
+    for l in range(1, 8):
+        stage0 = X3_STAGE["l1"] + 4 * (l - 1) if l <= 4 else (X3_STAGE["l5"] if l == 5 else X3_STAGE["l6"] + 4 * (l - 6))
+        act, regs = w.frags_of(w.layer(stage0, 8, act + (pe_f if l == 5 else []), C_BIAS8 + l * 256), True)
+    sig = np.zeros(64)
+    for i in range(128):
+        sig += regs[i] * cst[C_DENSW + HALF * 128 + i]
+    sigma = sig[:32] + sig[32:] + cst[C_DENSB]
+    g, _ = w.frags_of(w.layer(X3_STAGE["rgbf"], 8, act, C_BIAS8 + 8 * 256), False)
+    _, r = w.frags_of(w.layer(X3_STAGE["rgbh"], 4, g + qe_f, C_BIAS4), True)
+    rgb = np.zeros((3, 32))
+    for c in range(3):
+        v = np.zeros(64)
+        for i in range(64):
+            v += r[i] * cst[C_RGBW + c * 128 + HALF * 64 + i]
+        rgb[c] = v[:32] + v[32:] + cst[C_RGBB + c]
+    e, _ = w.frags_of(w.layer(X3_STAGE["insf"], 8, act, C_BIAS8 + 9 * 256), False)
+    s, _ = w.frags_of(w.layer(X3_STAGE["insh"], 4, e, C_BIAS4 + 128), True)
+    # ins_linear bias slots are [h*64 + i] whatever T is
+    acc3 = np.zeros((T, 32, 32))
+    for t in range(T):
+        for i in range(16):
+            for h in range(2):
+                acc3[t, (i & 3) + 8 * (i >> 2) + 4 * h, :] = cst[C_BIASO + h * 64 + 16 * t + i]
+    nk = 8
+    for t in range(T):
+        for ks in range(nk):
+            chunk = X3_STAGE["inso"] * 64 + (t * nk + ks) * 2
+            a = stream[chunk * X3_CHUNK:(chunk + 1) * X3_CHUNK].reshape(64, 8)
+            A = np.zeros((32, 16)); B = np.zeros((16, 32))
+            for j in range(8):
+                A[P, 8 * HALF + j] = a[:, j]
+                B[8 * HALF + j, P] = s[ks][j]
+            acc3[t] += A @ B
+    ins = acc3.reshape(T * 32, 32)[: ins_num + 1]
+    return np.concatenate([rgb, sigma[None], ins], 0).T
+
+
+@pytest.mark.parametrize("ins_num,seed", [(13, 0), (93, 3)])
+def test_x3_blob_consumed_in_mfma_order_equals_oracle_field(ins_num, seed):
+    lib = dm_nerf_amd.load_library()
+    n = lib.dmn_field_pack_index_x3_len(ins_num)
+    assert n == CONST + 44 * 64 * X3_CHUNK
+    assert lib.dmn_field_blob_x3_bytes(ins_num) == CONST * 4 + 44 * 64 * 1024
+    idx = np.empty(n, dtype=np.int32)
+    assert lib.dmn_field_pack_index_x3(ins_num, idx.ctypes.data) == 0
+    params = oracle.make_params(ins_num, seed)
+    flat = np.concatenate([params[k].numpy().reshape(-1) for k, _ in oracle.param_specs(ins_num)])
+    x, v = cases.field_rows()
+    emb = torch.cat([oracle.encode(torch.from_numpy(x[:32]), 10), oracle.encode(torch.from_numpy(v[:32]), 4)], -1)
+    with torch.no_grad():
+        want = oracle.field(params, emb).numpy()
+    got = simulate_x3(idx, flat, emb.numpy().astype(np.float64), ins_num)
+    assert rel_err(got, want) < 5e-6
+    # every weight appears exactly twice in the stream (hi chunk and lo chunk), every bias/head value once
+    used = np.bincount(idx[CONST:][idx[CONST:] >= 0], minlength=flat.size)
+    assert set(np.unique(used)) <= {0, 2}
+    both = np.bincount(idx[idx >= 0], minlength=flat.size)
+    assert both.min() >= 1

@@ -9,7 +9,9 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_long, c_void_p
 from typing import Optional
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libdmnerf_hip.so")
+# DMNERF_LIB points at an alternative build of the same ABI (timing-only ablation builds, tools/ablate.sh)
+LIB_PATH = os.environ.get("DMNERF_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc",
+                                                        "libdmnerf_hip.so")
 
 OK = 0
 ABI_VERSION = 1

@@ -17,7 +17,10 @@ SOURCES = ["field_fwd.hip", "field_fwd_x3.hip", "render_ops.hip", "field_pack.cp
 HEADERS = ["field_layout.h", "field_common.h", "trig.h", os.path.join("..", "..", "include", "dmnerf_hip.h")]
 # -ffp-contract=off: the path reproduces separately rounded fp32 multiplies and adds of the
 # reference (e.g. pts = o + d*z feeds a 2^9 frequency band); fused multiply-adds are explicit.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
+# -pragma-unroll-threshold: the field kernels are fully unrolled on purpose (register arrays need
+# compile-time indices); the default 16k-instruction cap would silently leave loops rolled -> scratch.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+         "-mllvm", "-pragma-unroll-threshold=400000"]
 
 
 def _stale() -> bool:

@@ -15,6 +15,7 @@ from .helpers import get_rays_k, sample_pdf, z_val_sample
 from .manipulator import manipulator_nerf, manipulator_render
 from .render import dm_nerf, render_train
 from .tester import render_image, render_test
+from . import parallel, trainer
 
 # nerf-pytorch names used by BASELINE.json's north_star
 render = dm_nerf
@@ -24,5 +25,6 @@ render_path = render_test
 __all__ = [
     "HipLibraryError", "LIB_PATH", "load_library", "create_nerf", "default_args", "DM_NeRF", "Embedder",
     "get_embedder", "get_rays_k", "sample_pdf", "z_val_sample", "manipulator_nerf", "manipulator_render",
-    "dm_nerf", "render_train", "render_image", "render_test", "render", "raw2outputs", "render_path",
+    "dm_nerf", "render_train", "render_image", "render_test", "render", "raw2outputs", "render_path", "parallel",
+    "trainer",
 ]

@@ -43,6 +43,7 @@ SIGNATURES = {
     "dmn_field_fwd_rays_x3": (c_int, [_P, _P, _P, c_long, c_long, c_int, _P, c_int, c_int, _P, _P, _P]),
     "dmn_field_fwd_embedded_x3": (c_int, [_P, c_long, _P, c_int, c_int, _P, _P, _P]),
     "dmn_composite_fwd": (c_int, [_P, _P, c_long, _P, c_long, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    "dmn_composite_bwd": (c_int, [_P, _P, c_long, _P, _P, _P, _P, _P, _P, c_long, c_int, c_int, c_int, _P, _P]),
     "dmn_sample_pdf": (c_int, [_P, c_long, _P, c_long, _P, c_long, c_long, c_int, c_int, _P, _P]),
     "dmn_resample_merge": (c_int, [_P, c_long, _P, _P, c_long, c_long, c_int, c_int, _P, _P]),
     "dmn_merge_depths": (c_int, [_P, c_long, c_int, _P, c_long, c_int, c_long, _P, _P]),

@@ -107,8 +107,8 @@ class DM_NeRF(nn.Module):
     def _refuse_grad(self):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError(
-                "dm_nerf_amd: the backward kernels are not built yet; call under torch.no_grad() "
-                "(the reference's test drivers do, test_dmsr.py:16)")
+                "dm_nerf_amd: DM_NeRF.forward(embedded) is an inference entry point (manipulator / mesh tools, "
+                "networks/manipulator.py:125-131); call it under torch.no_grad().  Training goes through dm_nerf().")
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         self._refuse_grad()

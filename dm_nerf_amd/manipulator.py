@@ -13,6 +13,9 @@ from .render import _check_embedders
 def manipulator_render(raw, z_vals, rays_d):
     """Compositing variant that keeps all ``ins_num + 1`` instance channels
     (networks/manipulator.py:86-105).  Returns ``(rgb_map, weights, depth_map, ins_map)``."""
+    if torch.is_grad_enabled() and raw.requires_grad:
+        raise NotImplementedError("manipulator_render is an inference path (it composites with undetached weights); "
+                                  "use torch.no_grad()")
     return ops.composite(raw, z_vals, rays_d, keep_last=True)
 
 

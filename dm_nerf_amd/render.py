@@ -8,6 +8,7 @@ from typing import Dict
 import torch
 
 from . import ops
+from .autograd import CompositeFn, FieldFn, needs_grad
 from .dm_nerf import DM_NeRF, Embedder
 from .helpers import _unit_linspace
 
@@ -16,7 +17,7 @@ def render_train(raw, z_vals, rays_d):
     """Alpha compositing ``(rgb_map, weights, depth_map, ins_map)`` (networks/render.py:6-28).
     ``ins_map`` has ``ins_num`` channels (the last, "air", logit channel is dropped, render.py:26)."""
     if torch.is_grad_enabled() and raw.requires_grad:
-        raise NotImplementedError("dm_nerf_amd: compositing backward is not built yet; use torch.no_grad()")
+        return CompositeFn.apply(raw, z_vals, rays_d)          # HIP forward + HIP backward
     return ops.composite(raw, z_vals, rays_d, keep_last=False)
 
 
@@ -43,8 +44,7 @@ def dm_nerf(rays, position_embedder, view_embedder, model_coarse, model_fine, z_
     _check_embedders(position_embedder, view_embedder)
     if not (isinstance(model_coarse, DM_NeRF) and isinstance(model_fine, DM_NeRF)):
         raise TypeError("model_coarse / model_fine must be dm_nerf_amd.DM_NeRF modules")
-    model_coarse._refuse_grad()
-    model_fine._refuse_grad()
+    train = needs_grad(model_coarse, model_fine)
     rays_o, rays_d = rays
     precision = getattr(args, "precision", None) or "fp32"
     n_importance = int(args.N_importance)
@@ -56,9 +56,14 @@ def dm_nerf(rays, position_embedder, view_embedder, model_coarse, model_fine, z_
             t_rand = torch.rand(z_vals_coarse.shape, device=rays_d.device)
         z_vals_coarse = ops.jitter_depths(z_vals_coarse, t_rand)                       # render.py:40-47
 
-    raw_coarse = ops.field_rays(rays_o, rays_d, z_vals_coarse, model_coarse.blob(precision), model_coarse.ins_num,
-                                precision)
-    rgb_coarse, weights_coarse, depth_coarse, ins_coarse = ops.composite(raw_coarse, z_vals_coarse, rays_d)
+    def field(model, z):
+        if train:       # outputs carry grad to the parameters (SURVEY.md section 8b "Autograd")
+            return FieldFn.apply(rays_o, rays_d, z, model, precision, *model.parameters())
+        return ops.field_rays(rays_o, rays_d, z, model.blob(precision), model.ins_num, precision)
+
+    raw_coarse = field(model_coarse, z_vals_coarse)
+    rgb_coarse, weights_coarse, depth_coarse, ins_coarse = render_train(raw_coarse, z_vals_coarse, rays_d)
+    weights_coarse = weights_coarse.detach()                                            # z_samples.detach(), render.py:68
 
     if n_importance > 0:
         if perturb == 0.0:
@@ -71,8 +76,8 @@ def dm_nerf(rays, position_embedder, view_embedder, model_coarse, model_fine, z_
         u = None
     z_vals_fine = ops.resample_merge(z_vals_coarse, weights_coarse, n_importance, u)    # render.py:66-70
 
-    raw_fine = ops.field_rays(rays_o, rays_d, z_vals_fine, model_fine.blob(precision), model_fine.ins_num, precision)
-    rgb_fine, _, depth_fine, ins_fine = ops.composite(raw_fine, z_vals_fine, rays_d)
+    raw_fine = field(model_fine, z_vals_fine)
+    rgb_fine, _, depth_fine, ins_fine = render_train(raw_fine, z_vals_fine, rays_d)
 
     if args.is_train and getattr(args, "N_ins", None) is not None:                      # render.py:88-90
         ins_fine = ins_fine[-args.N_ins:]

@@ -1,0 +1,74 @@
+"""Minimal training harness around the HIP render path: what the reference's ``train()`` does per iteration
+(train_dmsr.py:17-88), with the dataset / logging / flag plumbing left out (out of scope).
+
+    optimizer = make_optimizer(model_coarse, model_fine, lrate=5e-4)            # train_dmsr.py:127-128
+    losses = train_step(i, batch_rays, target_rgb, nerf, z_vals, optimizer, lrate=5e-4, lrate_decay=500,
+                        ins_loss=lambda pred: ins_criterion(pred, target_i, ins_num)[0],    # reference's own head
+                        penalizer=lambda raw, z, depth: ins_penalizer(raw, z, depth, rays_d, args))
+
+The instance-matching loss (``networks/evaluator.py:19-74``, scipy Hungarian on the host) and the emptiness
+penalizer (``networks/penalizer.py``) are the reference's PyTorch functions and plug in unchanged as callables;
+without them the step optimises the two colour terms only."""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional
+
+import torch
+
+from .render import dm_nerf
+
+
+def make_optimizer(model_coarse, model_fine, lrate: float = 5e-4) -> torch.optim.Optimizer:
+    """``Adam(coarse.parameters() + fine.parameters(), lr, betas=(0.9, 0.999))`` (train_dmsr.py:127-128)."""
+    return torch.optim.Adam(list(model_coarse.parameters()) + list(model_fine.parameters()), lr=lrate,
+                            betas=(0.9, 0.999))
+
+
+def decayed_lrate(i: int, lrate: float, lrate_decay: int) -> float:
+    """``lrate * 0.1 ** (i / (lrate_decay * 1000))`` (train_dmsr.py:68-70)."""
+    return lrate * (0.1 ** (i / (lrate_decay * 1000)))
+
+
+def train_step(i: int, batch_rays, target_rgb, nerf, z_vals_coarse, optimizer, lrate: float = 5e-4,
+               lrate_decay: int = 500, ins_loss: Optional[Callable] = None, penalizer: Optional[Callable] = None,
+               allreduce: Optional[Callable] = None) -> Dict[str, float]:
+    """One optimisation step (train_dmsr.py:32-72).  ``nerf`` is the tuple ``create_nerf`` returns.
+    ``allreduce(models)`` is called between backward and the optimizer step (data-parallel training:
+    ``dm_nerf_amd.parallel.allreduce_gradients``)."""
+    position_embedder, view_embedder, model_coarse, model_fine, args = nerf
+    out = dm_nerf(batch_rays, position_embedder, view_embedder, model_coarse, model_fine, z_vals_coarse, args)
+    mse_c = torch.mean((out["rgb_coarse"] - target_rgb) ** 2)                       # img2mse, evaluator.py:11
+    mse_f = torch.mean((out["rgb_fine"] - target_rgb) ** 2)
+    total = mse_f + mse_c
+    terms = {"rgb_coarse": mse_c, "rgb_fine": mse_f}
+    if ins_loss is not None:                                                        # train_dmsr.py:38-45
+        terms["ins_coarse"], terms["ins_fine"] = ins_loss(out["ins_coarse"]), ins_loss(out["ins_fine"])
+        total = total + terms["ins_coarse"] + terms["ins_fine"]
+    if penalizer is not None:                                                       # train_dmsr.py:53-60
+        terms["empty_coarse"] = penalizer(out["raw_coarse"], out["z_vals_coarse"], out["depth_coarse"])
+        terms["empty_fine"] = penalizer(out["raw_fine"], out["z_vals_fine"], out["depth_fine"])
+        total = total + terms["empty_coarse"] + terms["empty_fine"]
+    optimizer.zero_grad()
+    total.backward()
+    if allreduce is not None:
+        allreduce([model_coarse, model_fine])
+    optimizer.step()
+    for group in optimizer.param_groups:                                            # applied after the step, :68-72
+        group["lr"] = decayed_lrate(i, lrate, lrate_decay)
+    return {k: float(v) for k, v in terms.items()} | {"total": float(total),
+                                                      "psnr_fine": float(-10.0 * torch.log10(mse_f))}
+
+
+def checkpoint_dict(i: int, model_coarse, model_fine, optimizer) -> dict:
+    """The reference's checkpoint layout (train_dmsr.py:82-87)."""
+    return {"iteration": i, "network_coarse_state_dict": model_coarse.state_dict(),
+            "network_fine_state_dict": model_fine.state_dict(), "optimizer_state_dict": optimizer.state_dict()}
+
+
+def load_checkpoint(ckpt: dict, model_coarse, model_fine, optimizer=None) -> int:
+    """Counterpart of test_dmsr.py:93-109 (the reference's training scripts never resume; this one can)."""
+    model_coarse.load_state_dict(ckpt["network_coarse_state_dict"])
+    model_fine.load_state_dict(ckpt["network_fine_state_dict"])
+    if optimizer is not None and "optimizer_state_dict" in ckpt:
+        optimizer.load_state_dict(ckpt["optimizer_state_dict"])
+    return int(ckpt.get("iteration", 0))

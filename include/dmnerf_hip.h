@@ -103,6 +103,14 @@ int dmn_composite_fwd(const float* raw, const float* z, long z_ray_stride, const
                       int n_samples, int channels, int keep_last, float* rgb, float* weights, float* depth,
                       float* ins, void* stream);
 
+/* Backward of dmn_composite_fwd under the reference's autograd topology (networks/render.py:6-28: the
+ * instance map is built from weights.detach(), render.py:22-23): g_raw [N,S,C] from the gradients of
+ * rgb_map [N,3], depth_map [N], ins_map [N,K] (needs the forward's `ins` output) and weights [N,S];
+ * any gradient pointer may be NULL (= zero).                                                          */
+int dmn_composite_bwd(const float* raw, const float* z, long z_ray_stride, const float* rays_d, const float* ins,
+                      const float* g_rgb, const float* g_depth, const float* g_ins, const float* g_weights,
+                      long n_rays, int n_samples, int channels, int keep_last, float* g_raw, void* stream);
+
 /* ---- sample_pdf (networks/helpers.py:123-155) --------------------------------------------
  * bins [N, n_bins] (row stride bins_ray_stride, 0 = shared), weights [N, n_bins-1] (row stride
  * w_ray_stride, starting at `weights`), u: draw (n,k) = u[n * u_ray_stride + k] (stride 0 = one

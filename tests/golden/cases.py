@@ -117,3 +117,25 @@ def path_rays(n_rays: int, seed: int = 16):
     t_rand = rng.uniform(0, 1, size=(n_rays, N_SAMPLES)).astype(np.float32)
     u = rng.uniform(0, 1, size=(n_rays, N_IMPORTANCE)).astype(np.float32)
     return o.astype(np.float32).copy(), d.astype(np.float32), t_rand, u
+
+
+# ---- G7: gradient probe --------------------------------------------------------------
+PROBE_KEYS = ("rgb_fine", "ins_fine", "depth_fine", "rgb_coarse", "ins_coarse", "depth_coarse", "raw_fine",
+              "raw_coarse")
+
+
+def probe_weights(shapes: dict, seed: int = 17) -> dict:
+    """Fixed random linear functional of the render outputs: loss = sum_k <out_k, P_k>.  It reaches every
+    gradient path the training losses use (colour and instance maps, depth, and raw through the penalizer)
+    without dragging the loss heads (out of scope) into the fixture."""
+    rng = np.random.default_rng(seed)
+    return {k: rng.standard_normal(shapes[k]).astype(np.float32) for k in PROBE_KEYS}
+
+
+def grad_digest_slices(name: str, shape) -> tuple:
+    """Which part of a gradient tensor the fixture stores: everything for small tensors, a strided
+    subsample for the 256x256-class matrices (the per-tensor norms cover the rest)."""
+    n = int(np.prod(shape))
+    if n <= 4096:
+        return (slice(None),) * len(shape)
+    return (slice(None, None, 7), slice(None, None, 5))

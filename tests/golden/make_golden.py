@@ -187,9 +187,36 @@ def g8_image():
     save("g8_image.npz", rgb=torch.cat(rgb_parts).reshape(H, W, 3), ins=torch.cat(ins_parts).reshape(H, W, -1))
 
 
+def g7_gradients():
+    """One backward pass of the reference through dm_nerf with the stochastic path (recorded draws):
+    gradients of a fixed linear probe of the outputs w.r.t. every parameter of both networks."""
+    n = 48
+    o, d, t_rand, u = cases.path_rays(n, seed=18)
+    rays = torch.from_numpy(np.stack([o, d], 0))
+    pos_enc, dir_enc, coarse, fine = build_nets(13, 0, 1)
+    coarse.train(); fine.train()
+    z = ref_helpers.z_val_sample(n, cases.NEAR, cases.FAR, cases.N_SAMPLES)
+    args = SimpleNamespace(perturb=1.0, N_importance=cases.N_IMPORTANCE, is_train=True, N_ins=None)
+    with RandQueue([torch.from_numpy(t_rand), torch.from_numpy(u)]):
+        res = ref_render.dm_nerf(rays, pos_enc, dir_enc, coarse, fine, z, args)
+    probe = cases.probe_weights({k: tuple(res[k].shape) for k in cases.PROBE_KEYS})
+    loss = sum((res[k] * torch.from_numpy(probe[k])).sum() for k in cases.PROBE_KEYS)
+    loss.backward()
+    out = {"input_digest": cases.digest(o, d, t_rand, u), "loss": loss.detach(),
+           "z_vals_fine": res["z_vals_fine"].detach(), "z_vals_coarse": res["z_vals_coarse"].detach()}
+    for tag, net in (("c", coarse), ("f", fine)):
+        norms = []
+        for name, p in net.named_parameters():
+            g = p.grad.detach().numpy()
+            norms.append(np.linalg.norm(g.astype(np.float64)))
+            out[f"{tag}.{name}"] = g[cases.grad_digest_slices(name, g.shape)]
+        out[f"{tag}.norms"] = np.asarray(norms)
+    save("g7_gradients.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     table = {"g1": g1_rays, "g2": g2_encode, "g3": g3_field, "g4": g4_composite, "g5": g5_sampler,
-             "g6": g6_path, "g8": g8_image}
+             "g6": g6_path, "g7": g7_gradients, "g8": g8_image}
     for key in which:
         table[key]()

@@ -449,13 +449,130 @@ def test_fp16_range_flag_and_exact_fallback():
     assert np.isfinite(H(rgb_b)).all()
 
 
+# ---- training: gradients through the HIP path (row T / K11) --------------------------------------------
+def test_composite_backward_matches_oracle_autograd():
+    for (n, s, c, seed) in ((24, 64, 18, 141), (9, 192, 18, 142), (6, 100, 11, 144), (6, 64, 98, 143)):
+        raw, z, d = cases.composite_case(n, s, c, seed)
+        rng = np.random.default_rng(seed + 1)
+        probes = [rng.standard_normal(sh).astype(np.float32) for sh in ((n, 3), (n, s), (n,), (n, c - 5))]
+        raw_c = torch.from_numpy(raw).requires_grad_(True)
+        outs = oracle.composite(raw_c, torch.from_numpy(z), torch.from_numpy(d))
+        sum((o * torch.from_numpy(p)).sum() for o, p in zip(outs, probes)).backward()
+        raw_g = G(raw).requires_grad_(True)
+        outs_g = dm.render_train(raw_g, G(z), G(d))
+        sum((o * G(p)).sum() for o, p in zip(outs_g, probes)).backward()
+        err = rel_err(H(raw_g.grad), raw_c.grad.numpy())
+        assert err < 1e-4, (n, s, c, err)
+        # each gradient source on its own (NULL pointers for the others)
+        for k in range(4):
+            raw_g = G(raw).requires_grad_(True)
+            (dm.render_train(raw_g, G(z), G(d))[k] * G(probes[k])).sum().backward()
+            raw_c = torch.from_numpy(raw).requires_grad_(True)
+            (oracle.composite(raw_c, torch.from_numpy(z), torch.from_numpy(d))[k] * torch.from_numpy(probes[k])).sum().backward()
+            scale = max(float(raw_c.grad.abs().max()), 1e-30)
+            assert float(np.abs(H(raw_g.grad) - raw_c.grad.numpy()).max()) < 1e-4 * scale, (k, n, s, c)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
+def test_training_gradients_match_reference_golden(golden, precision):
+    """One backward pass through dm_nerf (stochastic path, recorded draws) against the reference's gradients."""
+    g = golden("g7_gradients.npz")
+    n = 48
+    o, d, t_rand, u = cases.path_rays(n, seed=18)
+    pos, view, coarse, fine, args = nets(13, 0, 1)
+    coarse.train(); fine.train()
+    args = SimpleNamespace(**{**vars(args), "perturb": 1.0, "is_train": True, "t_rand": G(t_rand), "u": G(u),
+                              "precision": precision})
+    z = dm.z_val_sample(n, cases.NEAR, cases.FAR, cases.N_SAMPLES)
+    res = dm.dm_nerf(G(np.stack([o, d], 0)), pos, view, coarse, fine, z, args)
+    assert res["rgb_fine"].requires_grad and res["raw_coarse"].requires_grad and not res["z_vals_fine"].requires_grad
+    probe = cases.probe_weights({k: tuple(res[k].shape) for k in cases.PROBE_KEYS})
+    loss = sum((res[k] * G(probe[k])).sum() for k in cases.PROBE_KEYS)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 2e-3 * abs(float(g["loss"]))   # sampler noise floor, see _check_path
+    worst = 0.0
+    for tag, net in (("c", coarse), ("f", fine)):
+        norms = np.array([np.linalg.norm(H(p.grad).astype(np.float64)) for p in net.parameters()])
+        np.testing.assert_allclose(norms, g[f"{tag}.norms"], rtol=5e-3)
+        for name, p in net.named_parameters():
+            got = H(p.grad)[cases.grad_digest_slices(name, p.shape)]
+            err = rel_err(got, g[f"{tag}.{name}"])
+            worst = max(worst, err)
+            # Coarse-network gradients do not see the sampler: 1e-4.  Fine-network gradients are evaluated at the
+            # resampled depths, and the reference disagrees with ITSELF there by 3.5e-2 (its fp64 run against
+            # these fp32 goldens; cumprod's backward divides by 1 - alpha + 1e-10): 5e-2 end to end, and
+            # test_fine_stage_gradients_on_golden_depths holds the fine stage itself to 5e-3.
+            assert err < (1e-4 if tag == "c" else 5e-2), (tag, name, err)
+    print(f"{precision}: worst gradient rel err {worst:.2e}")
+    # an optimizer step through the standard torch API works on the module's parameters (train_dmsr.py:127-128)
+    opt = torch.optim.Adam(list(coarse.parameters()) + list(fine.parameters()), lr=5e-4, betas=(0.9, 0.999))
+    before = coarse.blob().clone()
+    opt.step()
+    assert not torch.equal(before, coarse.blob())               # the packed weights follow the update
+
+
+def test_training_steps_reduce_loss_and_checkpoint_roundtrip(tmp_path):
+    """BASELINE config 4 shape in small: stochastic path, Adam(5e-4), lr decay after the step, reference
+    checkpoint keys (train_dmsr.py:82-87,127-128)."""
+    from dm_nerf_amd import trainer
+    pos, view, coarse, fine, args = nets(13, 0, 1)
+    coarse.train(); fine.train()
+    args.perturb, args.is_train = 1.0, True
+    n = 256
+    o, d, _, _ = cases.path_rays(n, seed=21)
+    rays = G(np.stack([o, d], 0))
+    target = torch.full((n, 3), 0.25, device=DEV)
+    z = dm.z_val_sample(n, cases.NEAR, cases.FAR, cases.N_SAMPLES)
+    opt = trainer.make_optimizer(coarse, fine, lrate=5e-4)
+    torch.manual_seed(3)
+    hist = [trainer.train_step(i, rays, target, (pos, view, coarse, fine, args), z, opt) for i in range(6)]
+    assert all(np.isfinite(h["total"]) for h in hist)
+    assert hist[-1]["total"] < hist[0]["total"]
+    assert abs(opt.param_groups[0]["lr"] - 5e-4 * 0.1 ** (5 / 500000)) < 1e-12
+    path = str(tmp_path / "000006.tar")
+    torch.save(trainer.checkpoint_dict(6, coarse, fine, opt), path)
+    ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    assert set(ckpt) == {"iteration", "network_coarse_state_dict", "network_fine_state_dict", "optimizer_state_dict"}
+    _, _, coarse2, fine2, _ = nets(13, 5, 6)
+    assert trainer.load_checkpoint(ckpt, coarse2, fine2) == 6
+    with torch.no_grad():
+        args.perturb, args.is_train = 0.0, False
+        a = dm.dm_nerf(rays[:, :32], pos, view, coarse, fine, z[:32], args)["rgb_fine"]
+        b = dm.dm_nerf(rays[:, :32], pos, view, coarse2, fine2, z[:32], args)["rgb_fine"]
+    np.testing.assert_array_equal(H(a), H(b))
+
+
+def test_fine_stage_gradients_on_golden_depths(golden):
+    """Fine field + compositing backward at the reference's own resampled depths (sampler out of the loop)."""
+    from dm_nerf_amd.autograd import FieldFn
+    g = golden("g7_gradients.npz")
+    n = 48
+    o, d, _, _ = cases.path_rays(n, seed=18)
+    _, _, _, fine, _ = nets(13, 0, 1)
+    z_fine = G(g["z_vals_fine"])
+    raw = FieldFn.apply(G(o), G(d), z_fine, fine, "fp32", *fine.parameters())
+    rgb, _, depth, ins = dm.render_train(raw, z_fine, G(d))
+    shapes = {"rgb_fine": (n, 3), "ins_fine": (n, 13), "depth_fine": (n,), "rgb_coarse": (n, 3), "ins_coarse": (n, 13),
+              "depth_coarse": (n,), "raw_fine": (n, 192, 18), "raw_coarse": (n, 64, 18)}
+    probe = cases.probe_weights(shapes)
+    ((rgb * G(probe["rgb_fine"])).sum() + (ins * G(probe["ins_fine"])).sum() + (depth * G(probe["depth_fine"])).sum()
+     + (raw * G(probe["raw_fine"])).sum()).backward()
+    for name, p in fine.named_parameters():
+        got = H(p.grad)[cases.grad_digest_slices(name, p.shape)]
+        # cumprod's backward divides by 1 - alpha + 1e-10, which magnifies the 1e-6 forward differences of
+        # saturated samples; observed 2.3e-3 worst (mlps.6.weight), 5e-3 allowed
+        assert rel_err(got, g[f"f.{name}"]) < 5e-3, name
+
+
 # ---- error behaviour ------------------------------------------------------------------------------
 def test_errors_are_python_exceptions():
     pos, view, coarse, fine, args = nets(13, 0, 1)
     rays = torch.zeros(2, 4, 3, device=DEV)
     z = dm.z_val_sample(4, 4.0, 15.0, 64)
-    with pytest.raises(NotImplementedError):                     # grad mode: backward kernels not built yet
-        dm.dm_nerf(rays, pos, view, coarse, fine, z, args)
+    with pytest.raises(NotImplementedError):                     # module call on encodings is inference-only
+        coarse(torch.zeros(4, 90, device=DEV))
+    with pytest.raises(NotImplementedError):
+        dm.manipulator_render(torch.zeros(4, 64, 18, device=DEV, requires_grad=True), z, rays[1])
     with pytest.raises(ValueError):
         dm.render_train(torch.zeros(4, 64, 18, device=DEV), torch.zeros(4, 32, device=DEV), rays[1])
     with pytest.raises(TypeError):

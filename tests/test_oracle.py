@@ -111,6 +111,28 @@ def test_g6_path(golden):
     assert det["raw_fine"].shape == (n, 192, 18) and det["ins_fine"].shape == (n, 13)
 
 
+def test_g7_gradients(golden):
+    """Backward through the oracle with the reference's detach topology against the reference's gradients."""
+    g = golden("g7_gradients.npz")
+    n = 48
+    o, d, t_rand, u = cases.path_rays(n, seed=18)
+    assert str(g["input_digest"]) == cases.digest(o, d, t_rand, u)
+    coarse = {k: v.requires_grad_(True) for k, v in oracle.make_params(13, 0).items()}
+    fine = {k: v.requires_grad_(True) for k, v in oracle.make_params(13, 1).items()}
+    z = oracle.coarse_depths(n, cases.NEAR, cases.FAR, cases.N_SAMPLES)
+    res = oracle.render_rays(T(np.stack([o, d], 0)), coarse, fine, z, perturb=1.0, t_rand=T(t_rand), u=T(u))
+    probe = cases.probe_weights({k: tuple(res[k].shape) for k in cases.PROBE_KEYS})
+    loss = sum((res[k] * T(probe[k])).sum() for k in cases.PROBE_KEYS)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    for tag, net in (("c", coarse), ("f", fine)):
+        norms = np.array([np.linalg.norm(p.grad.numpy().astype(np.float64)) for p in net.values()])
+        np.testing.assert_allclose(norms, g[f"{tag}.norms"], rtol=2e-4)
+        for name, p in net.items():
+            got = p.grad.numpy()[cases.grad_digest_slices(name, p.shape)]
+            assert rel_err(got, g[f"{tag}.{name}"]) < 2e-4, (tag, name)
+
+
 def test_g8_image(golden):
     g = golden("g8_image.npz")
     H, W = 20, 24

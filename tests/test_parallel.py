@@ -15,7 +15,7 @@ import torch.multiprocessing as mp
 
 import cases
 from oracle import dmnerf_cpu as oracle
-from dm_nerf_amd.parallel import gather_rays, max_over_ranks, pose_shard, ray_shard
+from dm_nerf_amd.parallel import allreduce_gradients, gather_rays, max_over_ranks, pose_shard, ray_shard
 
 H, W, CHUNK = 10, 12, 50
 
@@ -79,3 +79,34 @@ def test_two_rank_sharded_render_equals_single_rank(tmp_path):
     np.testing.assert_array_equal(got["full"][:, 0], np.arange(H * W, dtype=np.float32))   # placement exact
     np.testing.assert_allclose(got["full"][:, 1:], want[:, 1:], rtol=0, atol=1e-5)
     assert float(got["slowest"]) == 2.0
+
+
+def _grad_worker(rank, world, port, result_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        nets = [torch.nn.Linear(5, 3), torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.Linear(4, 2))]
+        x = torch.full((7, 5), float(rank + 1))                   # rank-dependent data -> rank-dependent grads
+        nets[1](nets[0](x)).sum().backward()
+        local = [p.grad.clone() for m in nets for p in m.parameters()]
+        n = allreduce_gradients(nets)
+        after = [p.grad.clone() for m in nets for p in m.parameters()]
+        torch.save({"n": n, "local": local, "after": after}, f"{result_path}.{rank}")
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_gradient_allreduce_two_ranks(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = str(tmp_path / "grads")
+    mp.spawn(_grad_worker, args=(2, port, base), nprocs=2, join=True)
+    r0, r1 = torch.load(base + ".0"), torch.load(base + ".1")
+    assert r0["n"] == r1["n"] == sum(g.numel() for g in r0["local"])
+    for a0, a1, l0, l1 in zip(r0["after"], r1["after"], r0["local"], r1["local"]):
+        torch.testing.assert_close(a0, a1, rtol=0, atol=0)          # every rank holds the same reduced gradient
+        torch.testing.assert_close(a0, (l0 + l1) / 2)               # the mean of the per-rank gradients

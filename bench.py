@@ -101,6 +101,8 @@ def main():
                     choices=["fp32", "fp16x3", "bf16x3"],
                     help="field-kernel arithmetic: fp32 = exact fp32 MFMA; fp16x3 / bf16x3 = three 16-bit MFMAs "
                          "per product (hi/lo split, fp32 accumulate)")
+    ap.add_argument("--no-fp32-leg", action="store_true",
+                    help="skip the extra 2 images rendered in exact-fp32 mode after the timed region (N = 1 only)")
     ns = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -198,6 +200,33 @@ def main():
                                "frac": comp_gbs / PEAK_HBM_GBS, "traffic": None, "launches": n_c,
                                "avg_launch_ms": t_c / max(n_c, 1) * 1e3, "time_share_of_step": t_c / elapsed},
     }
+
+    traffic_file = os.path.join(ROOT, "profiles", "composite_traffic.json")
+    if os.path.exists(traffic_file):        # HBM bytes per composite launch from rocprofv3 PMC passes (tools/pmc_l2.sh)
+        meas = json.load(open(traffic_file))
+        out["roofline_composite"]["traffic"] = meas["hbm_bytes_per_launch"]
+        out["roofline_composite"]["traffic_source"] = meas["source"]
+        out["roofline_composite"]["algorithmic_bytes_per_launch"] = comp_bytes / max(n_c, 1)
+
+    if x3 and world == 1 and not ns.no_fp32_leg:
+        # the same image once more with exact fp32 MFMA products, for reference beside the headline mode
+        args.precision = "fp32"
+        step()
+        torch.cuda.synchronize()
+        ops.PROFILE = []
+        t1 = time.perf_counter()
+        rgb32, _ = step()
+        torch.cuda.synchronize()
+        dt32 = time.perf_counter() - t1
+        prof32, ops.PROFILE = ops.PROFILE, None
+        rows = [(a.elapsed_time(b) * 1e-3, w) for k, a, b, w in prof32 if k == "field_fwd"]
+        tf32 = sum(w for _, w in rows) * FLOP_PER_POINT / sum(t for t, _ in rows) / 1e12
+        out["fp32_exact_mode"] = {"value": H * W / dt32, "unit": "rays/s", "ms_per_step": dt32 * 1e3,
+                                  "roofline": {"kernel": "field_fwd_kernel<1> (fp32 MFMA)", "bound": "mfma",
+                                               "achieved": tf32, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                               "frac": tf32 / PEAK_F32_MFMA_TFLOPS},
+                                  "max_abs_rgb_diff_vs_headline_mode": float((rgb32 - rgb).abs().max())}
+        args.precision = ns.precision
 
     if ns.cpu_rays > 0:
         cpu_rps, cpu_rgb, cpu_ins = cpu_baseline(K, pose, params, ns.cpu_rays, ns.chunk)

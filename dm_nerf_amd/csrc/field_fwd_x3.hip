@@ -13,8 +13,8 @@
 //     (128 registers of packed hi/lo halves) and of the layer being consumed both fit;
 //   * the epilogue of tile t-1 (ReLU, hi/lo split, range tracking) is spread over the k-steps of
 //     tile t so its VALU work runs in the shadow of the MFMAs;
-//   * 64 KiB stages (32 k-step/tile pairs x [hi, lo] chunk), double buffered, A fragments prefetched
-//     two steps ahead inside a stage.
+//   * 64 KiB stages (32 k-step/tile pairs x [hi, lo] chunk), double buffered; the LDS-DMA of the next stage
+//     is issued one 1 KiB piece per step; A fragments prefetched two steps ahead inside a stage.
 #include <hip/hip_runtime.h>
 
 #include "../../include/dmnerf_hip.h"
@@ -59,13 +59,23 @@ __device__ __forceinline__ void load_stage(const Ctx& c, int g) {
   for (int q = 0; q < 16; ++q) glds16(src + q * 1024, dst + q * 1024);
 }
 
-// Barrier that retires stage g (its DMA has landed, every wave is done with stage g-1), then the
-// prefetch of stage g+1 into the other buffer.
+// Barrier that retires stage g (its DMA has landed, every wave is done with stage g-1).  The DMA of stage
+// g+1 into the other buffer is NOT issued here: 4 waves x 16 pieces right behind the barrier queue up on the
+// CU's one address unit (16 cycles per 1 KiB piece) while the MFMAs wait in order behind them -- a quarter of
+// the kernel when measured.  load_piece() below spreads them one per step over the first half of the stage.
 __device__ __forceinline__ void stage_begin(Ctx& c) {
   __syncthreads();
-  if (c.g + 1 < c.G) load_stage(c, c.g + 1);
   c.buf = c.lds + (c.g & 1) * kX3StageBytes + c.lane * 16;
   ++c.g;
+}
+
+// piece q (0..15) of this wave's share of the NEXT stage (index c.g after stage_begin).  Past the end of the
+// stream the source clamps to the last stage and the copy lands in the buffer nobody reads any more.
+__device__ __forceinline__ void load_piece(const Ctx& c, int q) {
+  const int g = c.g < c.G ? c.g : c.G - 1;
+  const char* src = c.stream + (long)g * kX3StageBytes + (c.wave_s * 16 + q) * 1024 + c.lane * 16;
+  char* dst = c.lds + (c.g & 1) * kX3StageBytes + (c.wave_s * 16 + q) * 1024;
+  glds16(src, dst);
 }
 
 template <class P>
@@ -169,7 +179,12 @@ __device__ __forceinline__ void layer_x3(Ctx& c, const float* bias, const typena
       acc[t & 1] = P::mfma(ah[step % 3], bl, acc[t & 1]);
       acc[t & 1] = P::mfma(al[step % 3], bh, acc[t & 1]);
       acc[t & 1] = P::mfma(ah[step % 3], bh, acc[t & 1]);
+      if ((step & 31) < 16) load_piece(c, step & 31);     // one DMA piece per step, behind this step's MFMAs
     }
+  }
+  if ((STEPS & 31) != 0 && (STEPS & 31) < 16) {          // a short last stage still owes the rest of its pieces
+#pragma unroll
+    for (int q = (STEPS & 31); q < 16; ++q) load_piece(c, q);
   }
 #pragma unroll
   for (int q = 0; q < 8; ++q) epi(NT - 1, q, acc[(NT - 1) & 1]);

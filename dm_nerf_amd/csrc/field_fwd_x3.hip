@@ -22,6 +22,10 @@
 
 using namespace dmn;
 
+#ifndef DMN_X3_PREFETCH
+#define DMN_X3_PREFETCH 2
+#endif
+
 namespace {
 
 struct PrecF16 {
@@ -78,14 +82,22 @@ __device__ __forceinline__ void load_piece(const Ctx& c, int q) {
   glds16(src, dst);
 }
 
-template <class P>
+// PIN keeps the conversion where it is written (in the MFMA shadow of the next tile): without it the compiler
+// sinks all 128 conversions of a layer to their first use in the next layer and keeps 8 accumulators alive.
+template <class P, bool PIN = false>
 __device__ __forceinline__ void split_pair(float x0, float x1, typename P::frag& hi, typename P::frag& lo, int j) {
   typedef typename P::elem E;
-  const E h0 = (E)x0, h1 = (E)x1;
-  hi[j] = h0;
-  hi[j + 1] = h1;
-  lo[j] = (E)(x0 - (float)h0);
-  lo[j + 1] = (E)(x1 - (float)h1);
+  typedef E pair __attribute__((ext_vector_type(2)));
+  pair hp, lp;
+  hp[0] = (E)x0;
+  hp[1] = (E)x1;
+  lp[0] = (E)(x0 - (float)hp[0]);
+  lp[1] = (E)(x1 - (float)hp[1]);
+  if (PIN) asm volatile("" : "+v"(hp), "+v"(lp));
+  hi[j] = hp[0];
+  hi[j + 1] = hp[1];
+  lo[j] = lp[0];
+  lo[j + 1] = lp[1];
 }
 
 // ---- tile epilogues: piece q (0..7) handles accumulator registers 2q, 2q+1 of tile t -----------
@@ -100,13 +112,18 @@ struct EpiSplit {
   bool dens;
   __device__ __forceinline__ void operator()(int t, int q, const f32x16& acc) const {
     float x0 = acc[2 * q], x1 = acc[2 * q + 1];
-    if (RELU) {
-      x0 = fmaxf(x0, 0.f);
-      x1 = fmaxf(x1, 0.f);
+    if (RELU) {                              // v_med3_f32: one instruction, no canonicalising pre-max
+      x0 = __builtin_amdgcn_fmed3f(x0, 0.f, __builtin_inff());
+      x1 = __builtin_amdgcn_fmed3f(x1, 0.f, __builtin_inff());
     }
     if (dens) *sigma = fmaf(x1, dw[16 * t + 2 * q + 1], fmaf(x0, dw[16 * t + 2 * q], *sigma));
-    if (P::kCheckRange) *amax = fmaxf(*amax, fmaxf(fabsf(x0), fabsf(x1)));
-    split_pair<P>(x0, x1, oh[2 * t + (q >> 2)], ol[2 * t + (q >> 2)], (2 * q) & 7);
+    if (P::kCheckRange) {
+      *amax = fmaxf(*amax, fmaxf(fabsf(x0), fabsf(x1)));
+      // materialise the running maximum here: left free, LLVM reassociates the kernel-long max chain into one
+      // tree at the end of the kernel and keeps every converted value alive until then
+      asm volatile("" : "+v"(*amax));
+    }
+    split_pair<P, true>(x0, x1, oh[2 * t + (q >> 2)], ol[2 * t + (q >> 2)], (2 * q) & 7);
   }
 };
 // -> rgb_linear on the VALU (ReLU first; dm_nerf.py:91-93,102)
@@ -145,7 +162,8 @@ __device__ __forceinline__ void layer_x3(Ctx& c, const float* bias, const typena
   constexpr int STEPS = NT * NK;
   constexpr int PPS = (8 + NK - 1) / NK;   // epilogue pieces per k-step
   f32x16 acc[2];
-  frag ah[3], al[3];                       // A-fragment ring, indexed by step % 3
+  constexpr int PF = DMN_X3_PREFETCH;       // A-fragment prefetch distance in steps; ring of PF + 1
+  frag ah[PF + 1], al[PF + 1];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -159,15 +177,15 @@ __device__ __forceinline__ void layer_x3(Ctx& c, const float* bias, const typena
       if ((step & 31) == 0) {              // 32 steps = 64 chunks = one stage
         stage_begin(c);
 #pragma unroll
-        for (int d = 0; d < 2; ++d)
+        for (int d = 0; d < PF; ++d)
           if (step + d < STEPS) {
-            ah[(step + d) % 3] = *reinterpret_cast<const frag*>(c.buf + ((2 * (step + d)) & 63) * 1024);
-            al[(step + d) % 3] = *reinterpret_cast<const frag*>(c.buf + ((2 * (step + d) + 1) & 63) * 1024);
+            ah[(step + d) % (PF + 1)] = *reinterpret_cast<const frag*>(c.buf + ((2 * (step + d)) & 63) * 1024);
+            al[(step + d) % (PF + 1)] = *reinterpret_cast<const frag*>(c.buf + ((2 * (step + d) + 1) & 63) * 1024);
           }
       }
-      if (step + 2 < STEPS && ((step + 2) >> 5) == (step >> 5)) {   // two steps ahead, same stage
-        ah[(step + 2) % 3] = *reinterpret_cast<const frag*>(c.buf + ((2 * (step + 2)) & 63) * 1024);
-        al[(step + 2) % 3] = *reinterpret_cast<const frag*>(c.buf + ((2 * (step + 2) + 1) & 63) * 1024);
+      if (step + PF < STEPS && ((step + PF) >> 5) == (step >> 5)) {   // PF steps ahead, same stage
+        ah[(step + PF) % (PF + 1)] = *reinterpret_cast<const frag*>(c.buf + ((2 * (step + PF)) & 63) * 1024);
+        al[(step + PF) % (PF + 1)] = *reinterpret_cast<const frag*>(c.buf + ((2 * (step + PF) + 1) & 63) * 1024);
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above this step's MFMAs
       if (t > 0) {
@@ -176,9 +194,9 @@ __device__ __forceinline__ void layer_x3(Ctx& c, const float* bias, const typena
       }
       const frag bh = ks < NKS ? xh[ks < NKS ? ks : 0] : eh[ks < NKS ? 0 : ks - NKS];
       const frag bl = ks < NKS ? xl[ks < NKS ? ks : 0] : el[ks < NKS ? 0 : ks - NKS];
-      acc[t & 1] = P::mfma(ah[step % 3], bl, acc[t & 1]);
-      acc[t & 1] = P::mfma(al[step % 3], bh, acc[t & 1]);
-      acc[t & 1] = P::mfma(ah[step % 3], bh, acc[t & 1]);
+      acc[t & 1] = P::mfma(ah[step % (PF + 1)], bl, acc[t & 1]);
+      acc[t & 1] = P::mfma(al[step % (PF + 1)], bh, acc[t & 1]);
+      acc[t & 1] = P::mfma(ah[step % (PF + 1)], bh, acc[t & 1]);
       if ((step & 31) < 16) load_piece(c, step & 31);     // one DMA piece per step, behind this step's MFMAs
     }
   }

@@ -5,7 +5,7 @@ TAG=${1:?tag}; PREC=${2:-fp16x3}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$REPO/gpurun_out; mkdir -p "$OUT"
 export TMPDIR=/tmp; cd /tmp
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU GRBM_GUI_ACTIVE \
-  --output-format csv -d "$OUT/pmc_${TAG}" -- python3 $REPO/bench.py --steps 1 --warmup 0 --cpu-rays 0 --precision $PREC > "$OUT/pmc_${TAG}.log" 2>&1
+  --output-format csv -d "$OUT/pmc_${TAG}" -- python3 $REPO/bench.py --steps 1 --warmup 0 --cpu-rays 0 --no-fp32-leg --precision $PREC > "$OUT/pmc_${TAG}.log" 2>&1
 python3 - "$OUT/pmc_${TAG}" <<'PY'
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + '/**/*counter_collection.csv', recursive=True)[0]

@@ -7,7 +7,7 @@ export TMPDIR=/tmp; cd /tmp
 i=0
 for CTRS in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "FETCH_SIZE" "WRITE_SIZE TCC_EA0_RDREQ_sum"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d "$OUT/pmcl2_${TAG}_$i" -- python3 $REPO/bench.py --steps 1 --warmup 0 --cpu-rays 0 --precision $PREC > "$OUT/pmcl2_${TAG}_$i.log" 2>&1 || echo "pass $i failed"
+  rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d "$OUT/pmcl2_${TAG}_$i" -- python3 $REPO/bench.py --steps 1 --warmup 0 --cpu-rays 0 --no-fp32-leg --precision $PREC > "$OUT/pmcl2_${TAG}_$i.log" 2>&1 || echo "pass $i failed"
   python3 - "$OUT/pmcl2_${TAG}_$i" <<'PY'
 import csv, glob, sys, collections
 fs = glob.glob(sys.argv[1] + '/**/*counter_collection.csv', recursive=True)

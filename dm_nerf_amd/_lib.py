@@ -32,6 +32,7 @@ SIGNATURES = {
     "dmn_field_pack_index": (c_int, [c_int, _P]),
     "dmn_field_pack": (c_int, [_P, _P, c_long, _P, _P]),
     "dmn_raygen": (c_int, [c_int, c_int, c_float, c_float, c_float, c_float, c_float, _P, _P, _P, _P]),
+    "dmn_raygen_select": (c_int, [c_int, c_int, c_float, c_float, c_float, c_float, c_float, _P, _P, c_long, _P, _P, _P]),
     "dmn_jitter_depths": (c_int, [_P, c_long, _P, c_long, c_int, _P, _P]),
     "dmn_encode": (c_int, [_P, c_long, c_int, _P, _P]),
     "dmn_field_fwd_rays": (c_int, [_P, _P, _P, c_long, c_long, c_int, _P, c_int, _P, _P]),

@@ -86,6 +86,25 @@ __global__ void raygen_kernel(int H, int W, Camera cam, float* __restrict__ rays
   }
 }
 
+// rays of selected pixels only (training: get_select_full / get_select_crop, networks/helpers.py:64-111,
+// which build all H*W rays every step and then index them)
+__global__ void raygen_select_kernel(int W, Camera cam, const long* __restrict__ pixel, long n,
+                                     float* __restrict__ rays_o, float* __restrict__ rays_d) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long pix = pixel[i];
+    const int row = (int)(pix / W), col = (int)(pix - (long)row * W);
+    const float c0 = __fdiv_rn(__fsub_rn((float)col, cam.k02), cam.k00);
+    const float c1 = __fdiv_rn(__fsub_rn((float)row, cam.k12), cam.k11);
+    const float c2 = cam.k22;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      rays_d[3 * i + a] = __fadd_rn(__fadd_rn(__fmul_rn(c0, cam.r[3 * a + 0]), __fmul_rn(c1, cam.r[3 * a + 1])),
+                                    __fmul_rn(c2, cam.r[3 * a + 2]));
+      rays_o[3 * i + a] = cam.t[a];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // stratified jitter (networks/render.py:40-47)
 // ------------------------------------------------------------------------------------------
@@ -454,6 +473,22 @@ extern "C" int dmn_raygen(int H, int W, float k00, float k02, float k11, float k
   }
   hipLaunchKernelGGL(raygen_kernel, dim3(ew_blocks((long)H * W)), dim3(256), 0, (hipStream_t)stream, H, W, cam,
                      rays_o, rays_d);
+  return launch_status();
+}
+
+extern "C" int dmn_raygen_select(int H, int W, float k00, float k02, float k11, float k12, float k22,
+                                 const float* c2w, const long* pixel_index, long n, float* rays_o, float* rays_d,
+                                 void* stream) {
+  if (H <= 0 || W <= 0 || n < 0 || !c2w) return DMN_ERR_BAD_ARG;
+  if (n == 0) return DMN_OK;
+  if (!pixel_index || !rays_o || !rays_d) return DMN_ERR_BAD_ARG;
+  Camera cam{k00, k02, k11, k12, k22, {}, {}};
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) cam.r[3 * r + c] = c2w[4 * r + c];
+    cam.t[r] = c2w[4 * r + 3];
+  }
+  hipLaunchKernelGGL(raygen_select_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, W, cam, pixel_index,
+                     n, rays_o, rays_d);
   return launch_status();
 }
 

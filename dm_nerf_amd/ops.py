@@ -155,6 +155,24 @@ def raygen(H: int, W: int, K, c2w) -> Tuple[torch.Tensor, torch.Tensor]:
     return rays_o, rays_d
 
 
+def raygen_select(H: int, W: int, K, c2w, pixel_index: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Rays of the selected flat pixel indices only (int64 tensor on the device)."""
+    K = np.asarray(K, dtype=np.float64)
+    c2w_np = (c2w.detach().cpu().numpy() if torch.is_tensor(c2w) else np.asarray(c2w)).astype(np.float32)
+    c2w_np = np.ascontiguousarray(c2w_np[:3, :4])
+    if not pixel_index.is_cuda or pixel_index.dtype != torch.int64:
+        raise TypeError("pixel_index must be an int64 tensor on the ROCm device")
+    pixel_index = pixel_index.contiguous()
+    n = pixel_index.numel()
+    rays_o = torch.empty(n, 3, dtype=torch.float32, device=pixel_index.device)
+    rays_d = torch.empty(n, 3, dtype=torch.float32, device=pixel_index.device)
+    f32 = lambda v: float(np.float32(v))
+    check(load().dmn_raygen_select(H, W, f32(K[0, 0]), f32(K[0, 2]), f32(K[1, 1]), f32(K[1, 2]), f32(K[2, 2]),
+                                   c2w_np.ctypes.data, ptr(pixel_index), n, ptr(rays_o), ptr(rays_d),
+                                   current_stream()), "dmn_raygen_select")
+    return rays_o, rays_d
+
+
 def jitter_depths(z: torch.Tensor, t_rand: torch.Tensor) -> torch.Tensor:
     n, s = z.shape
     zz, stride = _rows(z, n, "z_vals")

@@ -62,6 +62,11 @@ int dmn_field_pack(const float* params, const int32_t* index, long blob_floats, 
 int dmn_raygen(int H, int W, float k00, float k02, float k11, float k12, float k22, const float* c2w_3x4_host,
                float* rays_o, float* rays_d, void* stream);
 
+/* Rays of n selected pixels (flat index row * W + col, int64, device) -- the ray part of get_select_full /
+ * get_select_crop (networks/helpers.py:64-111), without generating the other H*W - n rays.            */
+int dmn_raygen_select(int H, int W, float k00, float k02, float k11, float k12, float k22, const float* c2w_3x4_host,
+                      const long* pixel_index, long n, float* rays_o, float* rays_d, void* stream);
+
 /* ---- stratified jitter (networks/render.py:40-47) --------------------------------------- */
 int dmn_jitter_depths(const float* z, long z_ray_stride, const float* t_rand, long n_rays, int n_samples,
                       float* z_out, void* stream);

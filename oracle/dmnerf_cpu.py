@@ -312,3 +312,35 @@ def study_pose(index: int = 0) -> np.ndarray:
         c2w[:3, 3] = (0.3, -0.2, 6.0)
         return c2w
     return pose_spherical(-180.0 + 45.0 * index, -65.0, 7.0)
+
+
+# --------------------------------------------------------------------------------------
+# training ray selectors
+# --------------------------------------------------------------------------------------
+def select_full(rgb: torch.Tensor, pose: torch.Tensor, K, labels: torch.Tensor, picked) -> Tuple:
+    """``get_select_full`` (networks/helpers.py:99-111) with the host draw passed in: all H*W rays, then the
+    picked flat pixel indices.  Returns ``(target_c, target_i, batch_rays[2, N, 3])``."""
+    H, W = rgb.shape[:2]
+    rays_o, rays_d = rays_from_camera(H, W, K, pose)
+    idx = torch.as_tensor(np.asarray(picked), dtype=torch.long)
+    rows, cols = idx // W, idx % W
+    rays = torch.stack([rays_o[rows, cols], rays_d[rows, cols]], 0)
+    return rgb[rows, cols], labels[rows, cols], rays
+
+
+def select_crop(rgb, pose, K, labels, ins_index, crop_mask, n_train, labeled_pick, unlabeled_pick) -> Tuple:
+    """``get_select_crop`` (networks/helpers.py:64-95) with both draws passed in.  Labelled pixels (30 % of the
+    batch, at most ``len(ins_index)``) come last; the unlabelled positions index ``crop_indices`` directly, as the
+    reference does (:85-86).  Returns ``(target_c, target_i, batch_rays, N_ins)``."""
+    H, W = rgb.shape[:2]
+    ins_index = np.asarray(ins_index)
+    n_ins = min(int(n_train * 0.3), len(ins_index))
+    crop_indices = np.where(np.asarray(crop_mask).reshape(-1) == 1)[0]
+    labeled = ins_index[np.asarray(labeled_pick)]
+    unlabeled = crop_indices[np.asarray(unlabeled_pick)]
+    rays_o, rays_d = rays_from_camera(H, W, K, pose)
+    sel = torch.as_tensor(np.concatenate([unlabeled, labeled]), dtype=torch.long)
+    rows, cols = sel // W, sel % W
+    lab = torch.as_tensor(labeled, dtype=torch.long)
+    rays = torch.stack([rays_o[rows, cols], rays_d[rows, cols]], 0)
+    return rgb[rows, cols], labels[lab // W, lab % W], rays, n_ins

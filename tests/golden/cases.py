@@ -139,3 +139,26 @@ def grad_digest_slices(name: str, shape) -> tuple:
     if n <= 4096:
         return (slice(None),) * len(shape)
     return (slice(None, None, 7), slice(None, None, 5))
+
+
+# ---- G9: training ray selectors -----------------------------------------------------------
+def selector_case():
+    """A 12x16 image with labels, a pose, a crop rectangle with labelled pixels, and the recorded draws."""
+    H, W = 12, 16
+    rng = np.random.default_rng(19)
+    rgb = rng.uniform(0, 1, size=(H, W, 3)).astype(np.float32)
+    label = rng.integers(0, 5, size=(H, W)).astype(np.int64)
+    q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    pose = np.concatenate([q.astype(np.float32), np.array([[0.3], [-0.2], [6.0]], np.float32)], 1)   # 3x4
+    K = study_intrinsics(H, W)
+    n_train = 40
+    full_pick = rng.choice(H * W, size=n_train, replace=False)
+    crop_mask = np.zeros((H, W), np.int64)
+    crop_mask[2:10, 3:13] = 1
+    ins_index = np.nonzero((crop_mask.reshape(-1) == 1) & (rng.uniform(size=H * W) < 0.25))[0]      # labelled pixels
+    n_ins = min(int(n_train * 0.3), len(ins_index))
+    labeled_pick = rng.choice(len(ins_index), size=n_ins, replace=False)
+    n_unlabeled = int(crop_mask.sum()) - n_ins
+    unlabeled_pick = rng.choice(n_unlabeled, size=n_train - n_ins, replace=False)
+    return dict(H=H, W=W, rgb=rgb, label=label, pose=pose, K=K, n_train=n_train, full_pick=full_pick,
+                crop_mask=crop_mask, ins_index=ins_index, labeled_pick=labeled_pick, unlabeled_pick=unlabeled_pick)

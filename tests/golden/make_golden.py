@@ -214,9 +214,34 @@ def g7_gradients():
     save("g7_gradients.npz", **out)
 
 
+def g9_selectors():
+    """get_select_full / get_select_crop of the reference with its np.random.choice draws recorded."""
+    c = cases.selector_case()
+    draws = []
+
+    def fake_choice(a, size=None, replace=True):
+        return draws.pop(0)
+
+    orig = np.random.choice
+    np.random.choice = fake_choice
+    try:
+        draws[:] = [c["full_pick"]]
+        tc, ti, rays = ref_helpers.get_select_full(torch.from_numpy(c["rgb"]), torch.from_numpy(c["pose"]), c["K"],
+                                                   torch.from_numpy(c["label"]), c["n_train"])
+        draws[:] = [c["labeled_pick"], c["unlabeled_pick"]]
+        ctc, cti, crays, n_ins = ref_helpers.get_select_crop(torch.from_numpy(c["rgb"]), torch.from_numpy(c["pose"]),
+                                                             c["K"], torch.from_numpy(c["label"]), c["ins_index"],
+                                                             torch.from_numpy(c["crop_mask"]), c["n_train"])
+    finally:
+        np.random.choice = orig
+    save("g9_selectors.npz", input_digest=cases.digest(c["rgb"], c["label"], c["pose"], c["full_pick"], c["ins_index"]),
+         full_target_c=tc, full_target_i=ti, full_rays=rays, crop_target_c=ctc, crop_target_i=cti, crop_rays=crays,
+         crop_n_ins=n_ins)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     table = {"g1": g1_rays, "g2": g2_encode, "g3": g3_field, "g4": g4_composite, "g5": g5_sampler,
-             "g6": g6_path, "g7": g7_gradients, "g8": g8_image}
+             "g6": g6_path, "g7": g7_gradients, "g8": g8_image, "g9": g9_selectors}
     for key in which:
         table[key]()

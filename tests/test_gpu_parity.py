@@ -564,6 +564,32 @@ def test_fine_stage_gradients_on_golden_depths(golden):
         assert rel_err(got, g[f"f.{name}"]) < 5e-3, name
 
 
+# ---- training ray selectors (row N1) --------------------------------------------------------------------
+def test_ray_selectors_match_reference_golden(golden):
+    g = golden("g9_selectors.npz")
+    c = cases.selector_case()
+    tc, ti, rays = dm.get_select_full(G(c["rgb"]), c["pose"], c["K"], G(c["label"]), c["n_train"],
+                                      selected_index=c["full_pick"])
+    np.testing.assert_array_equal(H(tc), g["full_target_c"])
+    np.testing.assert_array_equal(H(ti), g["full_target_i"])
+    np.testing.assert_array_equal(H(rays[0]), g["full_rays"][0])
+    np.testing.assert_allclose(H(rays), g["full_rays"], rtol=0, atol=1e-6)
+    tc, ti, rays, n_ins = dm.get_select_crop(G(c["rgb"]), c["pose"], c["K"], G(c["label"]), c["ins_index"],
+                                             c["crop_mask"], c["n_train"], labeled_pick=c["labeled_pick"],
+                                             unlabeled_pick=c["unlabeled_pick"])
+    assert n_ins == int(g["crop_n_ins"]) and rays.shape == (2, c["n_train"], 3)
+    np.testing.assert_array_equal(H(tc), g["crop_target_c"])
+    np.testing.assert_array_equal(H(ti), g["crop_target_i"])
+    np.testing.assert_allclose(H(rays), g["crop_rays"], rtol=0, atol=1e-6)
+    # own draws: distinct pixels, right sizes, rays equal to the full-image generator at those pixels
+    tc, ti, rays = dm.get_select_full(G(c["rgb"]), c["pose"], c["K"], G(c["label"]), 64)
+    assert tc.shape == (64, 3) and ti.shape == (64,) and rays.shape == (2, 64, 3)
+    ro, rd = dm.get_rays_k(c["H"], c["W"], c["K"], c["pose"])
+    flat = rd.reshape(-1, 3)
+    match = (flat[None, :, :] == rays[1][:, None, :]).all(-1)
+    assert bool(match.any(1).all()) and int(match.any(0).sum()) == 64
+
+
 # ---- error behaviour ------------------------------------------------------------------------------
 def test_errors_are_python_exceptions():
     pos, view, coarse, fine, args = nets(13, 0, 1)

@@ -143,6 +143,22 @@ def test_g8_image(golden):
     assert rel_err(ins.numpy(), g["ins"]) < 2e-5
 
 
+def test_g9_selectors(golden):
+    g = golden("g9_selectors.npz")
+    c = cases.selector_case()
+    assert str(g["input_digest"]) == cases.digest(c["rgb"], c["label"], c["pose"], c["full_pick"], c["ins_index"])
+    tc, ti, rays = oracle.select_full(T(c["rgb"]), T(c["pose"]), c["K"], T(c["label"]), c["full_pick"])
+    np.testing.assert_array_equal(tc.numpy(), g["full_target_c"])
+    np.testing.assert_array_equal(ti.numpy(), g["full_target_i"])
+    np.testing.assert_allclose(rays.numpy(), g["full_rays"], rtol=0, atol=1e-6)
+    tc, ti, rays, n_ins = oracle.select_crop(T(c["rgb"]), T(c["pose"]), c["K"], T(c["label"]), c["ins_index"],
+                                             c["crop_mask"], c["n_train"], c["labeled_pick"], c["unlabeled_pick"])
+    assert n_ins == int(g["crop_n_ins"])
+    np.testing.assert_array_equal(tc.numpy(), g["crop_target_c"])
+    np.testing.assert_array_equal(ti.numpy(), g["crop_target_i"])
+    np.testing.assert_allclose(rays.numpy(), g["crop_rays"], rtol=0, atol=1e-6)
+
+
 def test_manipulator_variant_keeps_air_channel():
     # manipulator_render (networks/manipulator.py:86-105) is restated from text only: the module
     # does not import here (imageio/cv2/lpips absent) -> "parity unpinned" for this variant.

@@ -429,6 +429,27 @@ def test_split_precision_on_rays_and_whole_call(golden, precision):
     assert rel_err(raw, want) < 1e-4
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3", "bf16x3"])
+@pytest.mark.parametrize("ins_num", [0, 31, 32, 70, 100, 127])
+def test_every_instance_head_width_and_tiny_batches(precision, ins_num):
+    """All four ins_linear tile-count instantiations (1..4 tiles of 32 channels), single-ray and single-sample
+    launches, in every precision."""
+    rng = np.random.default_rng(ins_num)
+    params = oracle.make_params(ins_num, 11)
+    model = dm.DM_NeRF(8, 256, 63, 27, [4], ins_num).to(DEV)
+    model.load_state_dict(params)
+    for n_rays, n_samples in ((1, 1), (2, 33), (1, 130)):
+        o = rng.uniform(-1, 1, size=(n_rays, 3)).astype(np.float32)
+        d = rng.standard_normal((n_rays, 3)).astype(np.float32)
+        z = np.sort(rng.uniform(cases.NEAR, cases.FAR, size=(n_rays, n_samples)).astype(np.float32), -1)
+        raw = H(ops.field_rays(G(o), G(d), G(z), model.blob(precision), ins_num, precision))
+        with torch.no_grad():
+            want = oracle.field_on_rays(params, torch.from_numpy(o), torch.from_numpy(d), torch.from_numpy(z)).numpy()
+        assert raw.shape == (n_rays, n_samples, 5 + ins_num)
+        assert rel_err(raw, want) < 1e-4, (n_rays, n_samples)
+    assert ops.take_status(DEV) == 0
+
+
 def test_fp16_range_flag_and_exact_fallback():
     """Activations beyond the fp16 range must be flagged and the image re-rendered exactly."""
     pos, view, coarse, fine, args = nets(13, 0, 1)

@@ -214,7 +214,7 @@ def main():
     traffic_file = os.path.join(ROOT, "profiles", "composite_traffic.json")
     if os.path.exists(traffic_file):        # HBM bytes per composite launch from rocprofv3 PMC passes (tools/pmc_l2.sh)
         meas = json.load(open(traffic_file))
-        out["roofline_composite"]["traffic"] = meas["hbm_bytes_per_launch"]
+        out["roofline_composite"]["traffic"] = meas["hbm_bytes_per_ray"] * (pts_c // 256) / max(n_c, 1)   # per launch
         out["roofline_composite"]["traffic_source"] = meas["source"]
         out["roofline_composite"]["algorithmic_bytes_per_launch"] = comp_bytes / max(n_c, 1)
 

@@ -53,6 +53,9 @@ struct Ctx {
   const char* buf;      // this lane's read base inside the current stage
   int g, G;             // next stage to begin, number of stages
   int wave_s, lane;
+#ifdef DMN_STAMPS
+  unsigned long long t_dma = 0, t_bar = 0;
+#endif
 };
 
 // each wave DMA-copies 16 of the stage's 64 chunks
@@ -68,7 +71,20 @@ __device__ __forceinline__ void load_stage(const Ctx& c, int g) {
 // CU's one address unit (16 cycles per 1 KiB piece) while the MFMAs wait in order behind them -- a quarter of
 // the kernel when measured.  load_piece() below spreads them one per step over the first half of the stage.
 __device__ __forceinline__ void stage_begin(Ctx& c) {
+#ifdef DMN_STAMPS   // diagnostic build only (tools/stamps.sh): cycles spent waiting at the stage barrier
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
   __syncthreads();
+  const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  c.t_dma += t1 - t0;
+  c.t_bar += t2 - t1;
+#else
+  __syncthreads();
+#endif
   c.buf = c.lds + (c.g & 1) * kX3StageBytes + c.lane * 16;
   ++c.g;
 }
@@ -218,6 +234,10 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x3_kernel(const FieldArgs a)
   const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
   const char* const blob = static_cast<const char*>(a.blob);
   Ctx c{blob + kConstFloats * 4, lds, nullptr, 0, kX3Stages, wave_s, lane};
+#ifdef DMN_STAMPS
+  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
 
   for (int k = wave_s; k < kConstChunks; k += 4) glds16(blob + k * 1024 + lane * 16, lds + 2 * kX3StageBytes + k * 1024);
   load_stage(c, 0);
@@ -299,7 +319,20 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x3_kernel(const FieldArgs a)
   // ---- ins_linear: 128 -> ins_num + 1, T tiles, stored straight from the accumulators
   layer_x3<P, T, 8, 0>(c, cst + kConstBiasO + h * 64, act_h, act_l, pe_h, pe_l, EpiStore{out, a.ins_ch, h});
 
+#ifdef DMN_STAMPS
+  {
+    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    if (a.status != nullptr && lane == 0 && blockIdx.x % 97 == 0) {   // a sample of waves; status doubles as debug sink
+      atomicAdd(reinterpret_cast<unsigned long long*>(a.status) + 1, t_end - t_begin);
+      atomicAdd(reinterpret_cast<unsigned long long*>(a.status) + 2, c.t_dma);
+      atomicAdd(reinterpret_cast<unsigned long long*>(a.status) + 3, c.t_bar);
+      atomicAdd(reinterpret_cast<unsigned long long*>(a.status) + 4, 1ull);
+    }
+  }
+#else
   if (P::kCheckRange && a.status != nullptr && !(amax < 60000.f)) atomicOr(a.status, DMN_STATUS_FP16_RANGE);
+#endif
 }
 
 template <class P>

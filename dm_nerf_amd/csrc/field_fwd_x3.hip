@@ -236,6 +236,7 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x3_kernel(const FieldArgs a)
   Ctx c{blob + kConstFloats * 4, lds, nullptr, 0, kX3Stages, wave_s, lane};
 #ifdef DMN_STAMPS
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+  const unsigned long long r_begin = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz
   __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
 
@@ -322,12 +323,14 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x3_kernel(const FieldArgs a)
 #ifdef DMN_STAMPS
   {
     const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+    const unsigned long long r_end = __builtin_amdgcn_s_memrealtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);
     if (a.status != nullptr && lane == 0 && blockIdx.x % 97 == 0) {   // a sample of waves; status doubles as debug sink
       atomicAdd(reinterpret_cast<unsigned long long*>(a.status) + 1, t_end - t_begin);
       atomicAdd(reinterpret_cast<unsigned long long*>(a.status) + 2, c.t_dma);
       atomicAdd(reinterpret_cast<unsigned long long*>(a.status) + 3, c.t_bar);
       atomicAdd(reinterpret_cast<unsigned long long*>(a.status) + 4, 1ull);
+      atomicAdd(reinterpret_cast<unsigned long long*>(a.status) + 5, r_end - r_begin);
     }
   }
 #else

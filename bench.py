@@ -36,6 +36,9 @@ MACS_PER_POINT = 693_504                       # BASELINE.md section 3 (networks
 FLOP_PER_POINT = 2 * MACS_PER_POINT
 PEAK_F32_MFMA_TFLOPS = 157.3                   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_16BIT_MFMA_TFLOPS = 2500.0                # MI355X_MICROARCH.md: bf16 / f16 MFMA, dense (no sparsity)
+# measured with tools/mfma_peak.hip (register-only MFMA loop on all 256 CUs, random operands): the board power limit
+# pulls the engine clock to 1.70 / 1.87 GHz for f16 / bf16; fp32 MFMA holds 2.39 GHz
+SUSTAINED_MFMA_TFLOPS = {"fp16x3": 1738.0, "bf16x3": 1915.0, "fp32": 154.6}
 PEAK_HBM_GBS = 8000.0                          # MI355X_MICROARCH.md: HBM3E spec
 CPU_CHUNK = 4096                               # the reference's N_test (configs/test/dmsr/study.txt:10)
 
@@ -204,7 +207,12 @@ def main():
                      "mfma_flop_issued_per_algorithmic_flop": 3 if x3 else 1,
                      "launches": n_f, "avg_launch_ms": t_f / max(n_f, 1) * 1e3,
                      "algorithmic_flop_per_launch": pts_f * FLOP_PER_POINT / max(n_f, 1),
-                     "time_share_of_step": t_f / elapsed},
+                     "time_share_of_step": t_f / elapsed,
+                     # nominal peak is at 2.4 GHz; the device sustains less with every CU on 16-bit MFMA (board power
+                     # limit): tools/mfma_peak.hip, profiles/r01d_mfma_sustained_peak.txt
+                     "peak_sustained_measured": SUSTAINED_MFMA_TFLOPS[ns.precision],
+                     "mfma_issue_frac_of_sustained": (3 if x3 else 1) * field_tflops
+                                                     / SUSTAINED_MFMA_TFLOPS[ns.precision]},
         "roofline_composite": {"kernel": "composite_kernel (LDS-staged slabs + wave product scan)", "bound": "hbm",
                                "achieved": comp_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                "frac": comp_gbs / PEAK_HBM_GBS, "traffic": None, "launches": n_c,

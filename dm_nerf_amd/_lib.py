@@ -43,6 +43,16 @@ SIGNATURES = {
     "dmn_field_pack_x3": (c_int, [_P, _P, c_int, _P, _P]),
     "dmn_field_fwd_rays_x3": (c_int, [_P, _P, _P, c_long, c_long, c_int, _P, c_int, c_int, _P, _P, _P]),
     "dmn_field_fwd_embedded_x3": (c_int, [_P, c_long, _P, c_int, c_int, _P, _P, _P]),
+    "dmn_field_save_floats": (c_long, [c_long]),
+    "dmn_field_grad_floats": (c_long, [c_long, c_int]),
+    "dmn_field_fwd_rays_save": (c_int, [_P, _P, _P, c_long, c_long, c_int, _P, c_int, _P, _P, _P]),
+    "dmn_field_bwd_blob_floats": (c_long, [c_int]),
+    "dmn_field_bwd_pack_index": (c_int, [c_int, _P]),
+    "dmn_field_wgrad_index_len": (c_long, [c_int]),
+    "dmn_field_wgrad_index": (c_int, [c_int, _P]),
+    "dmn_field_bwd_data": (c_int, [_P, _P, _P, c_long, c_int, _P, _P]),
+    "dmn_field_wgrad_workspace_floats": (c_long, [c_int, c_int]),
+    "dmn_field_bwd_weights": (c_int, [_P, _P, c_long, c_int, _P, c_int, _P, _P, c_int, _P]),
     "dmn_composite_fwd": (c_int, [_P, _P, c_long, _P, c_long, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "dmn_composite_bwd": (c_int, [_P, _P, c_long, _P, _P, _P, _P, _P, _P, c_long, c_int, c_int, c_int, _P, _P]),
     "dmn_sample_pdf": (c_int, [_P, c_long, _P, c_long, _P, c_long, c_long, c_int, c_int, _P, _P]),

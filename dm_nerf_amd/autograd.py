@@ -4,10 +4,11 @@ Forward of both functions is the hand-written HIP kernel.  Backward:
 
 * ``CompositeFn``: hand-written HIP kernel (``dmn_composite_bwd``) with the reference's detach topology
   (the instance map is composited with ``weights.detach()``, networks/render.py:22-23).
-* ``FieldFn``: the 30 weight/bias gradients are dense GEMM work over all sample points.  This round they go
-  through library GEMMs (rocBLAS via torch) on activations that are recomputed from the saved rays and
-  depths with the same dataflow as the kernel (``torch_field_on_rays`` below); the fused MFMA backward is
-  the next step.  Nothing here runs on the CPU.
+* ``FieldFn``: hand-written HIP kernels (``csrc/field_bwd.hip``): the forward writes a save record, a fused
+  backward-data kernel chains dL/d pre-activation through the layers in registers, a split-K MFMA kernel reduces
+  the 30 weight/bias gradients over all sample points.  Under autograd the field always runs in exact fp32.
+  ``FieldFnLibrary`` (library GEMMs on recomputed activations, ``torch_field_on_rays``) is the cross-check.
+  Nothing here runs on the CPU.
 
 Only parameters receive gradients: rays and depths never need them (``z_samples.detach()``,
 networks/render.py:68)."""
@@ -57,7 +58,35 @@ def torch_field_on_rays(p: Dict[str, torch.Tensor], rays_o, rays_d, z) -> torch.
 
 
 class FieldFn(torch.autograd.Function):
-    """raw = field(rays, z; params).  forward: fused HIP kernel; backward: see module docstring."""
+    """raw = field(rays, z; params), hand-written HIP both ways: the exact-fp32 forward kernel also writes its save
+    record; backward = backward-data kernel (dL/d pre-activation of every layer, chained in registers) + split-K
+    weight-gradient kernel + scatter into the flat gradient (``ops.field_backward``)."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, z, model, precision, *params):
+        raw, save = ops.field_rays_save(rays_o, rays_d, z, model.blob("fp32"), model.ins_num)
+        ctx.save, ctx.model = save, model
+        ctx.meta = [(p.shape, p.numel(), p.requires_grad) for p in params]
+        return raw
+
+    @staticmethod
+    def backward(ctx, g_raw):
+        model = ctx.model
+        n_params = sum(n for _, n, _ in ctx.meta)
+        flat = ops.field_backward(g_raw, ctx.save, model.blob("bwd"), model.ins_num, model.wgrad_index(), n_params)
+        ctx.save = None
+        out: List = []
+        at = 0
+        for shape, n, wanted in ctx.meta:
+            out.append(flat[at:at + n].view(shape) if wanted else None)
+            at += n
+        return (None, None, None, None, None, *out)
+
+
+class FieldFnLibrary(torch.autograd.Function):
+    """Same function with the round-1 backward: parameter gradients through library GEMMs (rocBLAS via torch) on
+    activations recomputed from the saved rays and depths.  Kept as the on-device cross-check of ``FieldFn``
+    (tests) and for A/B timing (``FIELD_BACKWARD = "library"``)."""
 
     @staticmethod
     def forward(ctx, rays_o, rays_d, z, model, precision, *params):
@@ -78,6 +107,13 @@ class FieldFn(torch.autograd.Function):
         it = iter(grads)
         out: List = [next(it) if t.requires_grad else None for t in leaves]
         return (None, None, None, None, None, *out)
+
+
+FIELD_BACKWARD = "hip"          # "library": FieldFnLibrary
+
+
+def field_fn():
+    return FieldFn if FIELD_BACKWARD == "hip" else FieldFnLibrary
 
 
 class CompositeFn(torch.autograd.Function):

@@ -1,0 +1,399 @@
+// Backward of the fused field network for gfx950 (MI355X): what autograd runs for
+// networks/dm_nerf.py:80-106 in the reference's training step (train_dmsr.py:32-64), as three kernels.
+//
+//   field_bwd_data_kernel   dL/d(pre-activation) of every layer, chained in registers exactly like the forward
+//                           (transposed weights as the MFMA A operand, the previous gradient tile as B), ReLU
+//                           masks from the forward's save record, every layer's gradient tile written once as a
+//                           register image (field_layout.h "Training").  The instance branch stops at the trunk
+//                           output (h.detach(), dm_nerf.py:95).
+//   field_wgrad_kernel      dW = sum over points of G (x) X for the 17 (layer, input block) pairs, as split-K MFMA
+//                           GEMMs over the saved images: rows of 32 points are transposed through LDS into the
+//                           operand layout, each workgroup owns the whole [O x K] block for a slice of the points
+//                           and writes one partial; bias gradients (row sums of G) fall out of the staging loads.
+//   field_wgrad_reduce_kernel  sums the partials and scatters them into the flat parameter-gradient vector
+//                           (state_dict order) through the host-built table (field_pack.cpp).
+//
+// All arithmetic is fp32 (v_mfma_f32_32x32x2_f32).
+#include <hip/hip_runtime.h>
+
+#include "../../include/dmnerf_hip.h"
+#include "field_common.h"
+#include "field_stream.h"
+
+using namespace dmn;
+
+namespace {
+
+struct BwdArgs {
+  const float* g_raw;    // [M, C]  dL/d raw
+  const float* save;     // forward save record
+  const float* blob;     // backward-data blob
+  float* grad;           // gradient record (out)
+  long M;
+  int ins_ch;            // ins_num + 1
+};
+
+#define SRC_GI(i) gi[(i) < 16 * T ? (i) : 0]
+
+__device__ __forceinline__ bool mask_bit(const unsigned* m, int i) { return (m[i >> 5] >> (i & 31)) & 1u; }
+
+template <int T>
+__global__ __launch_bounds__(256, 1) void field_bwd_data_kernel(const BwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
+  float* const cst = lds + 2 * kStageFloats;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, p = lane & 31, h = lane >> 5;
+  const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float* const stream = a.blob + kConstFloats;
+  constexpr int G = bwd_total_stages(T);
+
+  for (int c = wave_s; c < kConstChunks; c += 4)
+    glds16(a.blob + c * kChunkFloats + lane * 4, cst + c * kChunkFloats);
+  load_stage(stream, 0, lds, wave_s, lane);
+
+  const long tile = (long)blockIdx.x * 4 + wave_s;
+  const long m = tile * 32 + p;
+  const bool valid = m < a.M;
+  const float* const srec = a.save + tile * kSaveTileFloats;
+  float* const grec = a.grad + tile * grad_tile_floats(T);
+
+  // ---- dL/d raw of this lane's point: rgb(3), sigma, instance logits in the ins_linear tile layout
+  float gi[16 * T];
+  float g_rgb[3] = {0.f, 0.f, 0.f}, g_sig = 0.f;
+  {
+    const int C = 4 + a.ins_ch;
+    const float* row = a.g_raw + (valid ? m : 0) * C;
+    if (valid) {
+      g_rgb[0] = row[0]; g_rgb[1] = row[1]; g_rgb[2] = row[2]; g_sig = row[3];
+    }
+#pragma unroll
+    for (int i = 0; i < 16 * T; ++i) {
+      const int ch = feat_of(i, 0) + 4 * h;
+      gi[i] = (valid && ch < a.ins_ch) ? row[4 + (ch < a.ins_ch ? ch : 0)] : 0.f;
+      image_store(grec, kGradHead + i, lane, gi[i]);
+    }
+    image_store(grec, kGradHead + 16 * T + 0, lane, h ? g_rgb[1] : g_rgb[0]);
+    image_store(grec, kGradHead + 16 * T + 1, lane, h ? g_sig : g_rgb[2]);
+#pragma unroll
+    for (int i = 2; i < 16; ++i) image_store(grec, kGradHead + 16 * T + i, lane, 0.f);
+  }
+
+  f32x16 acc[8];
+  f32x16 acc2[4];
+  float act[128];
+  unsigned msk[4];
+  int g = 0;
+  const float* buf;
+
+  // ---- instance branch: ins_linear^T, ReLU mask of ins_feature_linears.0, then its transpose
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
+#pragma unroll
+  for (int st = 0; st < bwd_inso_stages(T); ++st) {
+    buf = stage_begin(stream, g, G, lds, wave_s, lane);
+    constexpr int kAll = 16 * T;
+    const int nk = kAll - 32 * st < 32 ? kAll - 32 * st : 32;
+    if (nk == 32) { DMN_STAGE4(buf, SRC_GI, 32 * st, 32) }
+    else if (nk == 16) { DMN_STAGE4(buf, SRC_GI, 32 * st, 16) }
+    ++g;
+  }
+  msk[0] = __float_as_uint(image_load(srec, kSaveMaskI1 + 0, lane));
+  msk[1] = __float_as_uint(image_load(srec, kSaveMaskI1 + 1, lane));
+#pragma unroll
+  for (int i = 0; i < 64; ++i) {
+    const float v = mask_bit(msk, i) ? acc2[i >> 4][i & 15] : 0.f;
+    acc2[i >> 4][i & 15] = v;
+    image_store(grec, kGradI1 + i, lane, v);
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    buf = stage_begin(stream, g, G, lds, wave_s, lane);
+    DMN_STAGE8(buf, SRC_ACC2, 16 * s)
+    ++g;
+  }
+#pragma unroll
+  for (int i = 0; i < 128; ++i) image_store(grec, kGradInsF + i, lane, acc[i >> 4][i & 15]);
+
+  // ---- colour branch: rgb_linear^T on the VALU, ReLU mask of rgb_feature_linears.0, its transpose (feature
+  //      columns only: the view encoding needs no gradient), rgb_feature_linear^T
+  msk[0] = __float_as_uint(image_load(srec, kSaveMaskR1 + 0, lane));
+  msk[1] = __float_as_uint(image_load(srec, kSaveMaskR1 + 1, lane));
+#pragma unroll
+  for (int i = 0; i < 64; ++i) {
+    float v = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v = fmaf(g_rgb[c], cst[kConstRgbW + c * 128 + h * 64 + i], v);
+    v = mask_bit(msk, i) ? v : 0.f;
+    acc2[i >> 4][i & 15] = v;
+    image_store(grec, kGradR1 + i, lane, v);
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    buf = stage_begin(stream, g, G, lds, wave_s, lane);
+    DMN_STAGE8(buf, SRC_ACC2, 16 * s)
+    ++g;
+  }
+#pragma unroll
+  for (int i = 0; i < 128; ++i) {
+    act[i] = acc[i >> 4][i & 15];
+    image_store(grec, kGradFeat + i, lane, act[i]);
+  }
+
+  // ---- trunk output: rgb_feature_linear^T + density_linear^T, then mlps.7 .. mlps.1 transposed
+#pragma unroll 1
+  for (int l = 8; l >= 1; --l) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) msk[w] = __float_as_uint(image_load(srec + (save_mask(1) + 4 * (l - 1)) * 64, w, lane));
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      buf = stage_begin(stream, g, G, lds, wave_s, lane);
+      DMN_STAGE8(buf, SRC_ACT, 16 * s)
+      ++g;
+    }
+    float* const out = grec + (kGradA + 128 * (l - 1)) * 64;
+    const float sig = l == 8 ? g_sig : 0.f;          // density_linear reads h_8 (dm_nerf.py:101)
+#pragma unroll
+    for (int i = 0; i < 128; ++i) {
+      float v = acc[i >> 4][i & 15];
+      v = fmaf(sig, cst[kConstDensW + h * 128 + i], v);
+      v = mask_bit(msk, i) ? v : 0.f;
+      act[i] = v;
+      image_store(out, i, lane, v);
+    }
+  }
+}
+
+// ================================================================================================
+// weight gradients
+struct WgArgs {
+  const float* save;
+  const float* grad;
+  float* partial;          // [splits][index_len]
+  long n_tiles;            // 32-point tiles
+  long grad_tile_floats;
+  long index_len;
+  int splits;
+  WGemm gemm[kWGemms];
+  int list[kWGemms];       // blockIdx.y -> gemm id (GEMMs of one shape class per launch)
+};
+
+// OT x KT tiles of 32 x 32; the four waves form a WR x WC grid, each owning (OT/WR) x (KT/WC) tiles
+template <int OT, int KT, int WR, int WC>
+__global__ __launch_bounds__(256, 1) void field_wgrad_kernel(const WgArgs a) {
+  constexpr int R = 32 * (OT + KT);        // rows staged per point tile: G rows, then X rows
+  constexpr int RS = R + 2;                // LDS row stride of the [point][row] tile (2 mod 16: conflict-free)
+  constexpr int NP = OT + KT;              // 16-byte pieces per lane per tile (8 pieces per 128-byte row)
+  constexpr int OTW = OT / WR, KTW = KT / WC;
+  static_assert(WR * WC == 4 && OTW * WR == OT && KTW * WC == KT && OTW * KTW <= 16, "wave grid");
+  __shared__ __attribute__((aligned(16))) float lds[2 * 32 * RS];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, l = lane & 31, kh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WC, wc = wave % WC;
+  const WGemm gm = a.gemm[a.list[blockIdx.y]];
+  const long per = (a.n_tiles + a.splits - 1) / a.splits;
+  const long t0 = (long)blockIdx.x * per;
+  const long t1 = t0 + per < a.n_tiles ? t0 + per : a.n_tiles;
+  float* const part = a.partial + (long)blockIdx.x * a.index_len;
+
+  f32x16 acc[OTW * KTW];
+#pragma unroll
+  for (int n = 0; n < OTW * KTW; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+  float bsum[OT];
+#pragma unroll
+  for (int i = 0; i < OT; ++i) bsum[i] = 0.f;
+
+  // piece q = it*256 + tid: row q>>3 (G rows first), points 4*(q&7)..+3
+  const int prow = tid >> 3, ppc = tid & 7;
+  f32x4 stg[NP];
+  auto fetch = [&](long tile) {
+    const float* gsrc = a.grad + tile * a.grad_tile_floats + gm.g_reg * 64 + tid * 4;
+    const float* xsrc = a.save + tile * kSaveTileFloats + gm.x_reg * 64 + tid * 4;
+#pragma unroll
+    for (int it = 0; it < OT; ++it) stg[it] = *reinterpret_cast<const f32x4*>(gsrc + it * 1024);
+#pragma unroll
+    for (int it = 0; it < KT; ++it) stg[OT + it] = *reinterpret_cast<const f32x4*>(xsrc + it * 1024);
+  };
+  auto stage = [&](float* buf) {
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+      float* d = buf + (4 * ppc) * RS + it * 32 + prow;
+      d[0 * RS] = stg[it].x;
+      d[1 * RS] = stg[it].y;
+      d[2 * RS] = stg[it].z;
+      d[3 * RS] = stg[it].w;
+      if (it < OT) bsum[it < OT ? it : 0] += (stg[it].x + stg[it].y) + (stg[it].z + stg[it].w);
+    }
+  };
+
+  if (t0 < t1) {
+    fetch(t0);
+    stage(lds);
+  }
+  __syncthreads();
+  for (long t = t0; t < t1; ++t) {
+    const float* buf = lds + ((t - t0) & 1) * (32 * RS);
+    if (t + 1 < t1) fetch(t + 1);
+    // k-step ks: lane-half kh multiplies point ks + 16*kh (any bijection works: both operands use the same one)
+    const float* pa = buf + (16 * kh) * RS + wr * OTW * 32 + l;
+    const float* pb = buf + (16 * kh) * RS + OT * 32 + wc * KTW * 32 + l;
+    float fa[OTW], fb[KTW];
+#pragma unroll
+    for (int i = 0; i < OTW; ++i) fa[i] = pa[i * 32];
+#pragma unroll
+    for (int j = 0; j < KTW; ++j) fb[j] = pb[j * 32];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      float na[OTW], nb[KTW];
+#pragma unroll
+      for (int i = 0; i < OTW; ++i) na[i] = ks + 1 < 16 ? pa[(ks + 1) * RS + i * 32] : 0.f;
+#pragma unroll
+      for (int j = 0; j < KTW; ++j) nb[j] = ks + 1 < 16 ? pb[(ks + 1) * RS + j * 32] : 0.f;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < OTW; ++i)
+#pragma unroll
+        for (int j = 0; j < KTW; ++j) acc[i * KTW + j] = DMN_MFMA(fa[i], fb[j], acc[i * KTW + j]);
+#pragma unroll
+      for (int i = 0; i < OTW; ++i) fa[i] = na[i];
+#pragma unroll
+      for (int j = 0; j < KTW; ++j) fb[j] = nb[j];
+    }
+    if (t + 1 < t1) stage(lds + ((t + 1 - t0) & 1) * (32 * RS));
+    __syncthreads();
+  }
+
+  // ---- partial [O][K] block (MFMA C layout: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+  constexpr int K = KT * 32;
+#pragma unroll
+  for (int i = 0; i < OTW; ++i)
+#pragma unroll
+    for (int j = 0; j < KTW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = (wr * OTW + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int k = (wc * KTW + j) * 32 + l;
+        part[gm.index_off + o * K + k] = acc[i * KTW + j][r];
+      }
+  if (gm.bias_off >= 0) {
+#pragma unroll
+    for (int it = 0; it < OT; ++it) {
+      float v = bsum[it];
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      v += __shfl_xor(v, 4);
+      if (ppc == 0) part[gm.bias_off + it * 32 + prow] = v;
+    }
+  }
+}
+
+__global__ void field_wgrad_reduce_kernel(const float* partial, const int32_t* index, long index_len, int splits,
+                                          float* grads, int accumulate) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= index_len) return;
+  const int dst = index[e];
+  if (dst < 0) return;
+  float v = 0.f;
+  for (int s = 0; s < splits; ++s) v += partial[(long)s * index_len + e];
+  grads[dst] = accumulate ? grads[dst] + v : v;
+}
+
+template <int OT, int KT, int WR, int WC>
+void launch_class(WgArgs& a, const int* ids, int n, hipStream_t st) {
+  for (int i = 0; i < n; ++i) a.list[i] = ids[i];
+  hipLaunchKernelGGL((field_wgrad_kernel<OT, KT, WR, WC>), dim3(a.splits, n), dim3(256), 0, st, a);
+}
+
+}  // namespace
+
+extern "C" long dmn_field_grad_floats(long n_points, int ins_num) {
+  if (n_points < 0 || ins_num < 0 || ins_tiles(ins_num) > kMaxInsTiles) return DMN_ERR_BAD_ARG;
+  return ((n_points + 127) / 128) * 4 * grad_tile_floats(ins_tiles(ins_num));
+}
+
+extern "C" int dmn_field_bwd_data(const float* g_raw, const float* save, const float* bwd_blob, long n_points,
+                                  int ins_num, float* grad_record, void* stream) {
+  if (n_points < 0 || ins_num < 0) return DMN_ERR_BAD_ARG;
+  if (n_points == 0) return DMN_OK;
+  if (!g_raw || !save || !bwd_blob || !grad_record) return DMN_ERR_BAD_ARG;
+  const int T = ins_tiles(ins_num);
+  if (T > kMaxInsTiles) return DMN_ERR_UNSUPPORTED;
+  const long blocks = (n_points + 127) / 128;
+  if (blocks > 0x7fffffffL) return DMN_ERR_UNSUPPORTED;
+  const BwdArgs a{g_raw, save, bwd_blob, grad_record, n_points, ins_num + 1};
+  const dim3 grid((unsigned)blocks), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  switch (T) {
+    case 1: hipLaunchKernelGGL(field_bwd_data_kernel<1>, grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL(field_bwd_data_kernel<2>, grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL(field_bwd_data_kernel<3>, grid, block, 0, st, a); break;
+    case 4: hipLaunchKernelGGL(field_bwd_data_kernel<4>, grid, block, 0, st, a); break;
+  }
+  return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
+}
+
+extern "C" long dmn_field_wgrad_workspace_floats(int ins_num, int splits) {
+  if (ins_num < 0 || ins_tiles(ins_num) > kMaxInsTiles || splits <= 0) return DMN_ERR_BAD_ARG;
+  return (long)splits * wgrad_index_len(ins_tiles(ins_num));
+}
+
+extern "C" int dmn_field_bwd_weights(const float* save, const float* grad_record, long n_points, int ins_num,
+                                     const int32_t* wgrad_index, int splits, float* workspace, float* grads_flat,
+                                     int accumulate, void* stream) {
+  if (n_points < 0 || ins_num < 0 || splits <= 0 || splits > 65535) return DMN_ERR_BAD_ARG;
+  if (n_points == 0) return DMN_OK;
+  if (!save || !grad_record || !wgrad_index || !workspace || !grads_flat) return DMN_ERR_BAD_ARG;
+  const int T = ins_tiles(ins_num);
+  if (T > kMaxInsTiles) return DMN_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  WgArgs a{};
+  a.save = save;
+  a.grad = grad_record;
+  a.partial = workspace;
+  a.n_tiles = ((n_points + 127) / 128) * 4;
+  a.grad_tile_floats = grad_tile_floats(T);
+  a.index_len = wgrad_index_len(T);
+  a.splits = splits;
+  wgemm_table(T, a.gemm);
+  {
+    const int big[] = {1, 2, 3, 4, 5, 7, 8, 9, 10};
+    launch_class<8, 8, 2, 2>(a, big, 9, st);
+    const int pe[] = {0, 6};
+    launch_class<8, 2, 4, 1>(a, pe, 2, st);
+    const int half[] = {11, 13};
+    launch_class<4, 8, 2, 2>(a, half, 2, st);
+    const int view[] = {12};
+    launch_class<4, 1, 4, 1>(a, view, 1, st);
+    const int rgbo[] = {15};
+    launch_class<1, 4, 1, 4>(a, rgbo, 1, st);
+    const int dens[] = {16};
+    launch_class<1, 8, 1, 4>(a, dens, 1, st);
+    const int inso[] = {14};
+    switch (T) {
+      case 1: launch_class<1, 4, 1, 4>(a, inso, 1, st); break;
+      case 2: launch_class<2, 4, 2, 2>(a, inso, 1, st); break;
+      case 3: launch_class<3, 4, 1, 4>(a, inso, 1, st); break;
+      case 4: launch_class<4, 4, 2, 2>(a, inso, 1, st); break;
+    }
+  }
+  const long n = a.index_len;
+  hipLaunchKernelGGL(field_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace,
+                     wgrad_index, n, splits, grads_flat, accumulate);
+  return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
+}

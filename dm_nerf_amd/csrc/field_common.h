@@ -25,7 +25,12 @@ struct FieldArgs {
   long M;                // number of points
   int S;                 // samples per ray (rays mode)
   int ins_ch;            // ins_num + 1
+  float* save;           // training: save record per 32-point tile (field_layout.h), or null
 };
+
+// register image access: register `reg` of this wave's tile record (wave-uniform base, one 256-byte row)
+__device__ __forceinline__ void image_store(float* rec, int reg, int lane, float v) { rec[reg * 64 + lane] = v; }
+__device__ __forceinline__ float image_load(const float* rec, int reg, int lane) { return rec[reg * 64 + lane]; }
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
   // LDS destination is wave-uniform base + lane*16 (hardware rule); g is per lane.

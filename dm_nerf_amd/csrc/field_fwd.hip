@@ -19,111 +19,28 @@
 
 #include "../../include/dmnerf_hip.h"
 #include "field_common.h"
+#include "field_stream.h"
 
 using namespace dmn;
 
-#define DMN_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
-
 namespace {
 
-constexpr int kLdsFloats = 2 * kStageFloats + kConstFloats;   // 80,896 B
-
-// each wave DMA-copies 8 of the stage's 32 chunks
-__device__ __forceinline__ void load_stage(const float* stream, int g, float* buf, int wave_s, int lane) {
-  const float* src = stream + (long)g * kStageFloats + wave_s * 8 * kChunkFloats + lane * 4;
-  float* dst = buf + wave_s * 8 * kChunkFloats;
+// training: store N post-ReLU registers as an image plus their sign bits (bit b of word w <-> register 32w + b)
+template <int N>
+__device__ __forceinline__ void save_relu(float* img, float* msk, int lane, const float* v) {
 #pragma unroll
-  for (int q = 0; q < 8; ++q) glds16(src + q * kChunkFloats, dst + q * kChunkFloats);
-}
-
-// Barrier that retires stage g (DMA landed, everybody done with stage g-1), then prefetch of
-// stage g+1 into the other buffer.  Returns this lane's read base inside stage g.
-__device__ __forceinline__ const float* stage_begin(const float* stream, int g, int G, float* lds, int wave_s,
-                                                    int lane) {
-  __syncthreads();
-  if (g + 1 < G) load_stage(stream, g + 1, lds + ((g + 1) & 1) * kStageFloats, wave_s, lane);
-  return lds + (g & 1) * kStageFloats + lane * 4;
-}
-
-__device__ __forceinline__ void bias_tiles8(f32x16* acc, const float* b) {
+  for (int i = 0; i < N; ++i) image_store(img, i, lane, v[i]);
 #pragma unroll
-  for (int t = 0; t < 8; ++t)
+  for (int w = 0; w < N / 32; ++w) {
+    unsigned bits = 0;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const f32x4 x = *reinterpret_cast<const f32x4*>(b + t * 16 + v * 4);
-      acc[t][4 * v + 0] = x.x; acc[t][4 * v + 1] = x.y; acc[t][4 * v + 2] = x.z; acc[t][4 * v + 3] = x.w;
-    }
-}
-template <int NT>
-__device__ __forceinline__ void bias_tiles(f32x16* acc, const float* b) {
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const f32x4 x = *reinterpret_cast<const f32x4*>(b + t * 16 + v * 4);
-      acc[t][4 * v + 0] = x.x; acc[t][4 * v + 1] = x.y; acc[t][4 * v + 2] = x.z; acc[t][4 * v + 3] = x.w;
-    }
-}
-
-// 16 k-steps of an 8-tile layer out of one stage; B operand SRC(i) for k-step i
-#define DMN_STAGE8(BUF, SRC, BASE)                                                        \
-  {                                                                                       \
-    f32x4 a0 = *reinterpret_cast<const f32x4*>((BUF));                                    \
-    f32x4 a1 = *reinterpret_cast<const f32x4*>((BUF) + kChunkFloats);                     \
-    _Pragma("unroll") for (int jj = 0; jj < 16; ++jj) {                                   \
-      f32x4 n0 = a0, n1 = a1;                                                             \
-      if (jj + 1 < 16) { /* LDS reads of the next k-step fly under this k-step's MFMAs */ \
-        n0 = *reinterpret_cast<const f32x4*>((BUF) + (2 * jj + 2) * kChunkFloats);        \
-        n1 = *reinterpret_cast<const f32x4*>((BUF) + (2 * jj + 3) * kChunkFloats);        \
-      }                                                                                   \
-      __builtin_amdgcn_sched_barrier(0); /* keep the prefetch above the MFMAs */          \
-      const float bv = SRC((BASE) + jj);                                                  \
-      acc[0] = DMN_MFMA(a0.x, bv, acc[0]);                                                \
-      acc[1] = DMN_MFMA(a0.y, bv, acc[1]);                                                \
-      acc[2] = DMN_MFMA(a0.z, bv, acc[2]);                                                \
-      acc[3] = DMN_MFMA(a0.w, bv, acc[3]);                                                \
-      acc[4] = DMN_MFMA(a1.x, bv, acc[4]);                                                \
-      acc[5] = DMN_MFMA(a1.y, bv, acc[5]);                                                \
-      acc[6] = DMN_MFMA(a1.z, bv, acc[6]);                                                \
-      acc[7] = DMN_MFMA(a1.w, bv, acc[7]);                                                \
-      a0 = n0;                                                                            \
-      a1 = n1;                                                                            \
-    }                                                                                     \
+    for (int b = 0; b < 32; ++b) bits |= (v[32 * w + b] > 0.f ? 1u : 0u) << b;
+    image_store(msk, w, lane, __uint_as_float(bits));
   }
-// NK k-steps of a 4-tile layer out of one stage
-#define DMN_STAGE4(BUF, SRC, BASE, NK)                                                    \
-  {                                                                                       \
-    f32x4 a0 = *reinterpret_cast<const f32x4*>((BUF));                                    \
-    f32x4 a1 = *reinterpret_cast<const f32x4*>((BUF) + kChunkFloats);                     \
-    _Pragma("unroll") for (int jj = 0; jj < (NK); jj += 2) {                              \
-      f32x4 n0 = a0, n1 = a1;                                                             \
-      if (jj + 2 < (NK)) {                                                                \
-        n0 = *reinterpret_cast<const f32x4*>((BUF) + (jj + 2) * kChunkFloats);            \
-        n1 = *reinterpret_cast<const f32x4*>((BUF) + (jj + 3) * kChunkFloats);            \
-      }                                                                                   \
-      __builtin_amdgcn_sched_barrier(0);                                                  \
-      const float b0 = SRC((BASE) + jj);                                                  \
-      const float b1 = SRC((BASE) + jj + 1);                                              \
-      acc2[0] = DMN_MFMA(a0.x, b0, acc2[0]);                                              \
-      acc2[1] = DMN_MFMA(a0.y, b0, acc2[1]);                                              \
-      acc2[2] = DMN_MFMA(a0.z, b0, acc2[2]);                                              \
-      acc2[3] = DMN_MFMA(a0.w, b0, acc2[3]);                                              \
-      acc2[0] = DMN_MFMA(a1.x, b1, acc2[0]);                                              \
-      acc2[1] = DMN_MFMA(a1.y, b1, acc2[1]);                                              \
-      acc2[2] = DMN_MFMA(a1.z, b1, acc2[2]);                                              \
-      acc2[3] = DMN_MFMA(a1.w, b1, acc2[3]);                                              \
-      a0 = n0;                                                                            \
-      a1 = n1;                                                                            \
-    }                                                                                     \
-  }
+}
 
-#define SRC_ACT(i) act[(i)]
-#define SRC_PE(i) pe[(i)]
-#define SRC_QE(i) qe[(i)]
-#define SRC_ACC(i) acc[(i) >> 4][(i) & 15]
-#define SRC_ACC2(i) acc2[(i) >> 4][(i) & 15]
-
-template <int T>
+// SAVE: also write the save record the backward kernels read (field_layout.h "Training")
+template <int T, bool SAVE>
 __global__ __launch_bounds__(256, 1) void field_fwd_kernel(const FieldArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
   float* const cst = lds + 2 * kStageFloats;
@@ -145,6 +62,13 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(const FieldArgs a) {
 
   float pe[32], qe[16];
   point_encodings(a, mc, h, pe, qe);
+  float* const rec = SAVE ? a.save + ((long)blockIdx.x * 4 + wave_s) * kSaveTileFloats : nullptr;
+  if (SAVE) {
+#pragma unroll
+    for (int j = 0; j < 32; ++j) image_store(rec, kSavePe + j, lane, pe[j]);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) image_store(rec, kSaveQe + j, lane, qe[j]);
+  }
 
   f32x16 acc[8];
   float act[128];
@@ -161,6 +85,7 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(const FieldArgs a) {
   ++g;
 #pragma unroll
   for (int i = 0; i < 128; ++i) act[i] = fmaxf(acc[i >> 4][i & 15], 0.f);
+  if (SAVE) save_relu<128>(rec + save_h(1) * 64, rec + save_mask(1) * 64, lane, act);
 
   // ---- mlps.1 .. mlps.7 (mlps.5 also consumes the position encoding: skip connection)
 #pragma unroll 1
@@ -182,6 +107,7 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(const FieldArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < 128; ++i) act[i] = fmaxf(acc[i >> 4][i & 15], 0.f);
+    if (SAVE) save_relu<128>(rec + (save_h(1) + 128 * l) * 64, rec + (save_mask(1) + 4 * l) * 64, lane, act);
   }
 
   // ---- density_linear: 256 -> 1 on the VALU (dm_nerf.py:101)
@@ -202,6 +128,10 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(const FieldArgs a) {
     DMN_STAGE8(buf, SRC_ACT, 16 * s)
     ++g;
   }
+  if (SAVE) {
+#pragma unroll
+    for (int i = 0; i < 128; ++i) image_store(rec, kSaveFeat + i, lane, acc[i >> 4][i & 15]);
+  }
   // ---- rgb_feature_linears.0: cat([feature, dirs]) 283 -> 128, ReLU (dm_nerf.py:90-93)
   f32x16 acc2[4];
   bias_tiles<4>(acc2, cst + kConstBias4 + h * 64);
@@ -214,6 +144,12 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(const FieldArgs a) {
   buf = stage_begin(stream, g, G, lds, wave_s, lane);
   DMN_STAGE4(buf, SRC_QE, 0, 16)
   ++g;
+  if (SAVE) {
+    float r1[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) r1[i] = fmaxf(acc2[i >> 4][i & 15], 0.f);
+    save_relu<64>(rec + kSaveR1 * 64, rec + kSaveMaskR1 * 64, lane, r1);
+  }
   // ---- rgb_linear: 128 -> 3 on the VALU (dm_nerf.py:102)
   float rgb[3];
 #pragma unroll
@@ -234,6 +170,10 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(const FieldArgs a) {
     DMN_STAGE8(buf, SRC_ACT, 16 * s)
     ++g;
   }
+  if (SAVE) {
+#pragma unroll
+    for (int i = 0; i < 128; ++i) image_store(rec, kSaveInsF + i, lane, acc[i >> 4][i & 15]);
+  }
   // ---- ins_feature_linears.0: 256 -> 128, ReLU (dm_nerf.py:97-99)
   bias_tiles<4>(acc2, cst + kConstBias4 + 128 + h * 64);
 #pragma unroll
@@ -246,6 +186,12 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(const FieldArgs a) {
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[t][r] = fmaxf(acc2[t][r], 0.f);
+  if (SAVE) {
+    float i1[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) i1[i] = acc2[i >> 4][i & 15];
+    save_relu<64>(rec + kSaveI1 * 64, rec + kSaveMaskI1 * 64, lane, i1);
+  }
   // ---- ins_linear: 128 -> ins_num + 1 (dm_nerf.py:103), T output tiles
   f32x16 acc3[T];
   bias_tiles<T>(acc3, cst + kConstBiasO + h * 64);
@@ -288,20 +234,26 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(const FieldArgs a) {
   }
 }
 
-int launch_field(const FieldArgs& a, int ins_num, hipStream_t st) {
-  if (a.M <= 0) return DMN_OK;
-  const int T = ins_tiles(ins_num);
-  const long blocks = (a.M + 127) / 128;
-  if (blocks > 0x7fffffffL) return DMN_ERR_UNSUPPORTED;
-  const dim3 grid((unsigned)blocks), block(256);
+template <bool SAVE>
+int launch_field_t(const FieldArgs& a, int T, dim3 grid, hipStream_t st) {
+  const dim3 block(256);
   switch (T) {
-    case 1: hipLaunchKernelGGL(field_fwd_kernel<1>, grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL(field_fwd_kernel<2>, grid, block, 0, st, a); break;
-    case 3: hipLaunchKernelGGL(field_fwd_kernel<3>, grid, block, 0, st, a); break;
-    case 4: hipLaunchKernelGGL(field_fwd_kernel<4>, grid, block, 0, st, a); break;
+    case 1: hipLaunchKernelGGL((field_fwd_kernel<1, SAVE>), grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL((field_fwd_kernel<2, SAVE>), grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL((field_fwd_kernel<3, SAVE>), grid, block, 0, st, a); break;
+    case 4: hipLaunchKernelGGL((field_fwd_kernel<4, SAVE>), grid, block, 0, st, a); break;
     default: return DMN_ERR_UNSUPPORTED;
   }
   return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
+}
+
+int launch_field(const FieldArgs& a, int ins_num, hipStream_t st) {
+  if (a.M <= 0) return DMN_OK;
+  const long blocks = (a.M + 127) / 128;
+  if (blocks > 0x7fffffffL) return DMN_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)blocks);
+  return a.save ? launch_field_t<true>(a, ins_tiles(ins_num), grid, st)
+                : launch_field_t<false>(a, ins_tiles(ins_num), grid, st);
 }
 
 }  // namespace
@@ -314,7 +266,23 @@ extern "C" int dmn_field_fwd_rays(const float* rays_o, const float* rays_d, cons
   if (!rays_o || !rays_d || !z || !blob || !raw) return DMN_ERR_BAD_ARG;
   if (ins_tiles(ins_num) > kMaxInsTiles) return DMN_ERR_UNSUPPORTED;
   FieldArgs a{rays_o, rays_d, z, z_ray_stride, nullptr, blob, raw, nullptr, n_rays * (long)n_samples, n_samples,
-              ins_num + 1};
+              ins_num + 1, nullptr};
+  return launch_field(a, ins_num, (hipStream_t)stream);
+}
+
+extern "C" long dmn_field_save_floats(long n_points) {
+  return n_points < 0 ? DMN_ERR_BAD_ARG : ((n_points + 127) / 128) * 4 * kSaveTileFloats;
+}
+
+extern "C" int dmn_field_fwd_rays_save(const float* rays_o, const float* rays_d, const float* z, long z_ray_stride,
+                                       long n_rays, int n_samples, const float* blob, int ins_num, float* raw,
+                                       float* save, void* stream) {
+  if (n_rays < 0 || n_samples <= 0 || ins_num < 0 || z_ray_stride < 0) return DMN_ERR_BAD_ARG;
+  if (n_rays == 0) return DMN_OK;
+  if (!rays_o || !rays_d || !z || !blob || !raw || !save) return DMN_ERR_BAD_ARG;
+  if (ins_tiles(ins_num) > kMaxInsTiles) return DMN_ERR_UNSUPPORTED;
+  FieldArgs a{rays_o, rays_d, z, z_ray_stride, nullptr, blob, raw, nullptr, n_rays * (long)n_samples, n_samples,
+              ins_num + 1, save};
   return launch_field(a, ins_num, (hipStream_t)stream);
 }
 

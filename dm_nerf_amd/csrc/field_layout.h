@@ -160,4 +160,99 @@ constexpr long kX3StreamHalfs = (long)kX3Stages * kX3StageChunks * kX3ChunkHalfs
 constexpr long kX3BlobBytes = (long)kConstFloats * 4 + kX3StreamHalfs * 2;
 constexpr long kX3IndexLen = (long)kConstFloats + kX3StreamHalfs;   // one gather entry per float / half
 
+// =====================================================================================
+// Training (backward of the field; train_dmsr.py:32-64 drives it through autograd).
+//
+// Per-point state crosses HBM as "register images": what a wave of the field kernels holds for its 32
+// points, register by register -- image[reg i][lane] (64 lanes x 4 B = one 256-byte row), lane = point +
+// 32*half, and register i of half h is feature feat_of(i, h) (pos_slot / dir_slot for the encodings).
+// Seen as a matrix an image is [2*regs rows][32 points] with row r = 2*i + h.  Every store / load of the
+// producing kernels is one fully coalesced 256-byte wave access; the weight-gradient kernel reads rows.
+//
+// Save record of the forward (per 32-point tile, floats = kSaveRegs * 64):
+constexpr int kSavePe = 0;          // 32 regs: position encoding (GEMM input of mlps.0 and of the skip)
+constexpr int kSaveQe = 32;         // 16 regs: view encoding
+constexpr int kSaveH = 48;          // h_1 .. h_8 (post-ReLU trunk activations), 128 regs each
+constexpr int kSaveFeat = kSaveH + 8 * 128;      // rgb_feature_linear output (no activation), 128
+constexpr int kSaveR1 = kSaveFeat + 128;         // rgb_feature_linears.0 output (post-ReLU), 64
+constexpr int kSaveInsF = kSaveR1 + 64;          // ins_feature_linear output (no activation), 128
+constexpr int kSaveI1 = kSaveInsF + 128;         // ins_feature_linears.0 output (post-ReLU), 64
+constexpr int kSaveMask = kSaveI1 + 64;          // ReLU masks as bits: 4 regs per trunk layer (bit b of reg w
+                                                 // = register 32*w + b is positive), then 2 for r1, 2 for i1
+constexpr int kSaveRegs = kSaveMask + 8 * 4 + 2 + 2;          // 1492
+constexpr long kSaveTileFloats = (long)kSaveRegs * 64;
+DMN_HD constexpr int save_h(int l) { return kSaveH + 128 * (l - 1); }          // h_l, l = 1..8
+DMN_HD constexpr int save_mask(int l) { return kSaveMask + 4 * (l - 1); }      // mask of h_l
+constexpr int kSaveMaskR1 = kSaveMask + 32;
+constexpr int kSaveMaskI1 = kSaveMask + 34;
+
+// Gradient record written by the backward-data kernel (dL/d pre-activation of every layer), per tile:
+constexpr int kGradA = 0;           // G_0 .. G_7 (trunk), 128 regs each
+constexpr int kGradFeat = 8 * 128;  // dL/d rgb feature, 128
+constexpr int kGradR1 = kGradFeat + 128;         // 64
+constexpr int kGradInsF = kGradR1 + 64;          // 128
+constexpr int kGradI1 = kGradInsF + 128;         // 64
+constexpr int kGradHead = kGradI1 + 64;          // 16*T regs: dL/d ins logits (register 16t + r <-> channel
+                                                 // feat_of(16t + r, h)), then one 16-register tile whose
+                                                 // registers 0, 1 hold (g_rgb0 | g_rgb1) and (g_rgb2 | g_sigma)
+DMN_HD constexpr int grad_regs(int T) { return kGradHead + 16 * (T + 1); }
+DMN_HD constexpr long grad_tile_floats(int T) { return (long)grad_regs(T) * 64; }
+
+// Backward-data weight stream (exact fp32, same chunk / stage geometry as the forward stream, weights
+// transposed: a layer computes  G_in^T = W^T * G_out^T).  Const section = the forward's (the two VALU heads).
+DMN_HD constexpr int bwd_inso_stages(int T) { return T <= 2 ? 1 : 2; }   // W_io^T: 4 tiles x 16T k-steps, 1 chunk each
+DMN_HD constexpr int bwd_stage_insh(int T) { return bwd_inso_stages(T); }            // W_i1^T: 8 tiles x 64 k-steps -> 4
+DMN_HD constexpr int bwd_stage_rgbh(int T) { return bwd_stage_insh(T) + 4; }         // W_r1^T[:256]: 4 stages
+DMN_HD constexpr int bwd_stage_rgbf(int T) { return bwd_stage_rgbh(T) + 4; }         // W_rf^T: 8 stages
+DMN_HD constexpr int bwd_stage_mlp(int T, int l) { return bwd_stage_rgbf(T) + 8 + 8 * (7 - l); }   // l = 7..1
+DMN_HD constexpr int bwd_total_stages(int T) { return bwd_stage_rgbf(T) + 8 + 7 * 8; }
+DMN_HD constexpr long bwd_blob_floats(int ins_num) {
+  return (long)kConstFloats + (long)bwd_total_stages(ins_tiles(ins_num)) * kStageFloats;
+}
+
+// Weight-gradient GEMMs: dW[o][k] = sum over points of G[o][point] * X[k][point], G rows from the gradient
+// record, X rows from the save record (or, for the heads, G from the head tile).  Shapes in 32-row tiles.
+struct WGemm {
+  int g_reg, g_tiles;      // gradient-record register offset, row tiles (rows / 32 = regs / 16)
+  int x_reg, x_tiles;      // save-record register offset, row tiles
+  int index_off;           // offset of this GEMM's [g_tiles*32][x_tiles*32] scatter table (flat-parameter index or -1)
+  int bias_off;            // offset of its [g_tiles*32] bias scatter table, or -1
+};
+constexpr int kWGemms = 17;
+// The list (index_off / bias_off are running sums in list order; bias only where a layer's G appears first).
+inline void wgemm_table(int T, WGemm* g) {
+  int n = 0;
+  auto add = [&](int g_reg, int g_tiles, int x_reg, int x_tiles, bool bias) {
+    g[n++] = WGemm{g_reg, g_tiles, x_reg, x_tiles, 0, bias ? 0 : -1};
+  };
+  add(kGradA, 8, kSavePe, 2, true);                                        // 0  mlps.0
+  for (int l = 1; l <= 4; ++l) add(kGradA + 128 * l, 8, save_h(l), 8, true);   // 1-4
+  add(kGradA + 128 * 5, 8, save_h(5), 8, true);                            // 5  mlps.5, columns of h
+  add(kGradA + 128 * 5, 8, kSavePe, 2, false);                             // 6  mlps.5, columns of input_pts
+  add(kGradA + 128 * 6, 8, save_h(6), 8, true);                            // 7
+  add(kGradA + 128 * 7, 8, save_h(7), 8, true);                            // 8
+  add(kGradFeat, 8, save_h(8), 8, true);                                   // 9  rgb_feature_linear
+  add(kGradInsF, 8, save_h(8), 8, true);                                   // 10 ins_feature_linear
+  add(kGradR1, 4, kSaveFeat, 8, true);                                     // 11 rgb_feature_linears.0, feature columns
+  add(kGradR1, 4, kSaveQe, 1, false);                                      // 12 rgb_feature_linears.0, view columns
+  add(kGradI1, 4, kSaveInsF, 8, true);                                     // 13 ins_feature_linears.0
+  add(kGradHead, T, kSaveI1, 4, true);                                     // 14 ins_linear
+  add(kGradHead + 16 * T, 1, kSaveR1, 4, true);                            // 15 rgb_linear (rows rgb0..2)
+  add(kGradHead + 16 * T, 1, save_h(8), 8, true);                          // 16 density_linear (row sigma)
+  int off = 0;
+  for (int i = 0; i < kWGemms; ++i) { g[i].index_off = off; off += g[i].g_tiles * 32 * g[i].x_tiles * 32; }
+  for (int i = 0; i < kWGemms; ++i)
+    if (g[i].bias_off == 0) { g[i].bias_off = off; off += g[i].g_tiles * 32; }
+}
+inline long wgrad_index_len(int T) {
+  WGemm g[kWGemms];
+  wgemm_table(T, g);
+  long n = 0;
+  for (int i = 0; i < kWGemms; ++i) {
+    n += (long)g[i].g_tiles * 32 * g[i].x_tiles * 32;
+    if (g[i].bias_off >= 0) n += g[i].g_tiles * 32;
+  }
+  return n;
+}
+
 }  // namespace dmn

@@ -69,6 +69,29 @@ struct Builder {
         c[lane * 4 + e] = k < 0 ? -1 : w_off + row * fan_in + k;
       }
   }
+  // transposed variants for the backward-data stream: A[row][k] = W[kf][row], kf = feature held by k-step j
+  template <class Col>
+  void kstep8T(int stage0, int j, int w_off, int fan_in, Col kfeat) {
+    for (int q = 0; q < 2; ++q) {
+      int32_t* c = stream + ((long)stage0 * kStageChunks + 2 * j + q) * kChunkFloats;
+      for (int lane = 0; lane < 64; ++lane)
+        for (int e = 0; e < 4; ++e) {
+          int row = 32 * (4 * q + e) + (lane & 31);
+          int kf = kfeat(lane >> 5);
+          c[lane * 4 + e] = kf < 0 ? -1 : w_off + kf * fan_in + row;
+        }
+    }
+  }
+  template <class Col>
+  void kstep4T(int stage0, int j, int w_off, int fan_in, Col kfeat) {
+    int32_t* c = stream + ((long)stage0 * kStageChunks + j) * kChunkFloats;
+    for (int lane = 0; lane < 64; ++lane)
+      for (int e = 0; e < 4; ++e) {
+        int row = 32 * e + (lane & 31);
+        int kf = kfeat(lane >> 5);
+        c[lane * 4 + e] = kf < 0 ? -1 : w_off + kf * fan_in + row;
+      }
+  }
 };
 
 // ---- split-precision stream (v_mfma_f32_32x32x16_{f16,bf16}) ---------------------------------
@@ -188,5 +211,81 @@ extern "C" int dmn_field_pack_index_x3(int ins_num, int32_t* index_out) {
   layer_x3(s, kX3StageInsF, 8, 16, P.insf_w, kWidth, kWidth, act);
   layer_x3(s, kX3StageInsH, 4, 16, P.insh_w, kWidth, kHalf, act);
   layer_x3(s, kX3StageInsO, T, 8, P.inso_w, kHalf, ins_num + 1, act);
+  return DMN_OK;
+}
+
+// ---- training: backward-data stream and weight-gradient scatter tables -------------------------------
+extern "C" long dmn_field_bwd_blob_floats(int ins_num) {
+  if (!supported(ins_num)) return DMN_ERR_BAD_ARG;
+  return bwd_blob_floats(ins_num);
+}
+
+extern "C" int dmn_field_bwd_pack_index(int ins_num, int32_t* index_out) {
+  if (!index_out || !supported(ins_num)) return DMN_ERR_BAD_ARG;
+  const int T = ins_tiles(ins_num);
+  const ParamOffsets P = param_offsets(ins_num);
+  const long n = bwd_blob_floats(ins_num);
+  std::fill(index_out, index_out + n, -1);
+  fill_const(index_out, P, ins_num);
+  Builder b{index_out + kConstFloats};
+  for (int j = 0; j < 16 * T; ++j)                               // ins_linear^T: channels -> 128
+    b.kstep4T(0, j, P.inso_w, kHalf, [&](int h) { int ch = feat_of(j, h); return ch <= ins_num ? ch : -1; });
+  for (int j = 0; j < 64; ++j) {
+    b.kstep8T(bwd_stage_insh(T), j, P.insh_w, kWidth, [&](int h) { return feat_of(j, h); });          // [128 x 256]^T
+    b.kstep8T(bwd_stage_rgbh(T), j, P.rgbh_w, kWidth + kDirCh, [&](int h) { return feat_of(j, h); }); // first 256 columns
+  }
+  for (int j = 0; j < 128; ++j) {
+    b.kstep8T(bwd_stage_rgbf(T), j, P.rgbf_w, kWidth, [&](int h) { return feat_of(j, h); });
+    for (int l = 7; l >= 1; --l)
+      b.kstep8T(bwd_stage_mlp(T, l), j, P.mlp_w[l], mlp_fan_in(l), [&](int h) { return feat_of(j, h); });
+  }
+  return DMN_OK;
+}
+
+extern "C" long dmn_field_wgrad_index_len(int ins_num) {
+  if (!supported(ins_num)) return DMN_ERR_BAD_ARG;
+  return wgrad_index_len(ins_tiles(ins_num));
+}
+
+// Row r = 2*i + h of a register image -> column / row of the parameter it belongs to
+extern "C" int dmn_field_wgrad_index(int ins_num, int32_t* out) {
+  if (!out || !supported(ins_num)) return DMN_ERR_BAD_ARG;
+  const int T = ins_tiles(ins_num);
+  const ParamOffsets P = param_offsets(ins_num);
+  WGemm g[kWGemms];
+  wgemm_table(T, g);
+  auto act = [](int r) { return feat_of(r >> 1, r & 1); };
+  auto pos = [](int r) { return pos_slot(r >> 1, r & 1); };
+  auto dir = [](int r) { return dir_slot(r >> 1, r & 1); };
+  auto chan = [&](int r) { int c = feat_of(r >> 1, r & 1); return c <= ins_num ? c : -1; };
+  auto rgbrow = [](int r) { return r < 3 ? r : -1; };            // head tile rows: rgb0, rgb1, rgb2, sigma, 0...
+  auto sigrow = [](int r) { return r == 3 ? 0 : -1; };
+  // weight offset, fan-in, row map, column map (+ column base), bias offset
+  auto fill = [&](int gi, int w_off, int fan_in, int col0, auto rowmap, auto colmap, int b_off) {
+    const WGemm& G = g[gi];
+    const int O = G.g_tiles * 32, K = G.x_tiles * 32;
+    for (int o = 0; o < O; ++o) {
+      const int ro = rowmap(o);
+      for (int k = 0; k < K; ++k) {
+        const int ck = colmap(k);
+        out[G.index_off + o * K + k] = (ro < 0 || ck < 0) ? -1 : w_off + ro * fan_in + col0 + ck;
+      }
+      if (G.bias_off >= 0) out[G.bias_off + o] = ro < 0 ? -1 : b_off + ro;
+    }
+  };
+  fill(0, P.mlp_w[0], kPosCh, 0, act, pos, P.mlp_b[0]);
+  for (int l = 1; l <= 4; ++l) fill(l, P.mlp_w[l], kWidth, 0, act, act, P.mlp_b[l]);
+  fill(5, P.mlp_w[5], kWidth + kPosCh, 0, act, act, P.mlp_b[5]);
+  fill(6, P.mlp_w[5], kWidth + kPosCh, kWidth, act, pos, -1);
+  fill(7, P.mlp_w[6], kWidth, 0, act, act, P.mlp_b[6]);
+  fill(8, P.mlp_w[7], kWidth, 0, act, act, P.mlp_b[7]);
+  fill(9, P.rgbf_w, kWidth, 0, act, act, P.rgbf_b);
+  fill(10, P.insf_w, kWidth, 0, act, act, P.insf_b);
+  fill(11, P.rgbh_w, kWidth + kDirCh, 0, act, act, P.rgbh_b);
+  fill(12, P.rgbh_w, kWidth + kDirCh, kWidth, act, dir, -1);
+  fill(13, P.insh_w, kWidth, 0, act, act, P.insh_b);
+  fill(14, P.inso_w, kHalf, 0, chan, act, P.inso_b);
+  fill(15, P.rgbo_w, kHalf, 0, rgbrow, act, P.rgbo_b);
+  fill(16, P.dens_w, kWidth, 0, sigrow, act, P.dens_b);
   return DMN_OK;
 }

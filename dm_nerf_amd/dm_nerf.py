@@ -84,25 +84,35 @@ class DM_NeRF(nn.Module):
         return [p for _, p in self.named_parameters()]      # registration order = state_dict order
 
     def blob(self, precision: str = "fp32") -> torch.Tensor:
-        """Device blob consumed by the field kernel of the given precision; re-gathered only when a
-        parameter changed (optimizer steps and load_state_dict bump the tensors' version counters)."""
-        ops.precision_code(precision)
+        """Device blob consumed by the field kernel of the given precision ("bwd": the transposed-weight blob of
+        the backward-data kernel); re-gathered only when a parameter changed (optimizer steps and
+        load_state_dict bump the tensors' version counters)."""
+        if precision != "bwd":
+            ops.precision_code(precision)
         params = self._ordered_params()
         dev = params[0].device
         key = (dev, tuple((p.data_ptr(), p._version) for p in params))
         cached = self._blobs.get(precision)
         if cached is not None and cached[0] == key:
             return cached[1]
-        flavour = "fp32" if precision == "fp32" else "x3"
+        flavour = precision if precision in ("fp32", "bwd") else "x3"
         index = self._indices.get((flavour, dev))
         if index is None:
-            index = ops.pack_index(self.ins_num, dev) if flavour == "fp32" else ops.pack_index_x3(self.ins_num, dev)
-            self._indices[(flavour, dev)] = index
+            make = {"fp32": ops.pack_index, "bwd": ops.bwd_pack_index, "x3": ops.pack_index_x3}[flavour]
+            index = self._indices[(flavour, dev)] = make(self.ins_num, dev)
         with torch.no_grad():
             flat = torch.cat([p.detach().reshape(-1).float() for p in params])
-        blob = ops.pack_blob(flat, index) if flavour == "fp32" else ops.pack_blob_x3(flat, index, self.ins_num, precision)
+        blob = ops.pack_blob_x3(flat, index, self.ins_num, precision) if flavour == "x3" else ops.pack_blob(flat, index)
         self._blobs[precision] = (key, blob)
         return blob
+
+    def wgrad_index(self) -> torch.Tensor:
+        """Scatter table of the weight-gradient kernel (ops.field_backward) on the parameters' device."""
+        dev = self._ordered_params()[0].device
+        index = self._indices.get(("wgrad", dev))
+        if index is None:
+            index = self._indices[("wgrad", dev)] = ops.wgrad_index(self.ins_num, dev)
+        return index
 
     def _refuse_grad(self):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):

@@ -212,6 +212,70 @@ def field_rays(rays_o: torch.Tensor, rays_d: torch.Tensor, z: torch.Tensor, blob
     return raw
 
 
+# ---- training: forward with save record, backward-data + weight-gradient kernels ----------------
+def bwd_pack_index(ins_num: int, device) -> torch.Tensor:
+    lib = load()
+    n = lib.dmn_field_bwd_blob_floats(ins_num)
+    if n < 0:
+        raise ValueError(f"ins_num={ins_num} unsupported (ins_num + 1 must be <= {MAX_INS_CHANNELS})")
+    idx = np.empty(n, dtype=np.int32)
+    check(lib.dmn_field_bwd_pack_index(ins_num, idx.ctypes.data), "dmn_field_bwd_pack_index")
+    return torch.from_numpy(idx).to(device)
+
+
+def wgrad_index(ins_num: int, device) -> torch.Tensor:
+    lib = load()
+    n = lib.dmn_field_wgrad_index_len(ins_num)
+    if n < 0:
+        raise ValueError(f"ins_num={ins_num} unsupported (ins_num + 1 must be <= {MAX_INS_CHANNELS})")
+    idx = np.empty(n, dtype=np.int32)
+    check(lib.dmn_field_wgrad_index(ins_num, idx.ctypes.data), "dmn_field_wgrad_index")
+    return torch.from_numpy(idx).to(device)
+
+
+def field_rays_save(rays_o: torch.Tensor, rays_d: torch.Tensor, z: torch.Tensor, blob: torch.Tensor,
+                    ins_num: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Exact-fp32 field forward that also writes the save record the backward kernels read."""
+    n = rays_o.shape[0]
+    rays_o = _dev(rays_o, "rays_o").contiguous()
+    rays_d = _dev(rays_d, "rays_d").contiguous()
+    zz, stride = _rows(z, n, "z_vals")
+    s = z.shape[1]
+    raw = torch.empty(n, s, 5 + ins_num, dtype=torch.float32, device=rays_o.device)
+    save = torch.empty(load().dmn_field_save_floats(n * s), dtype=torch.float32, device=rays_o.device)
+    with _timed("field_fwd_save", n * s):
+        check(load().dmn_field_fwd_rays_save(ptr(rays_o), ptr(rays_d), ptr(zz), stride, n, s, ptr(blob), ins_num,
+                                             ptr(raw), ptr(save), current_stream()), "dmn_field_fwd_rays_save")
+    return raw, save
+
+
+def field_backward(g_raw: torch.Tensor, save: torch.Tensor, bwd_blob: torch.Tensor, ins_num: int,
+                   wgrad_idx: torch.Tensor, n_params: int, splits: Optional[int] = None) -> torch.Tensor:
+    """dL/d raw [N,S,C] + save record -> flat parameter gradient (state_dict order)."""
+    _dev(g_raw, "g_raw")
+    g_raw = g_raw.contiguous()
+    m = g_raw.shape[0] * g_raw.shape[1]
+    if g_raw.shape[2] != 5 + ins_num:
+        raise ValueError(f"g_raw must have {5 + ins_num} channels")
+    lib = load()
+    dev = g_raw.device
+    if save.numel() != lib.dmn_field_save_floats(m):
+        raise ValueError("save record does not belong to this many points")
+    n_tiles = (m + 127) // 128 * 4
+    if splits is None:
+        splits = max(1, min(85, n_tiles // 8))          # 9 big GEMMs x 85 slices = 3 workgroups per CU
+    grec = torch.empty(lib.dmn_field_grad_floats(m, ins_num), dtype=torch.float32, device=dev)
+    with _timed("field_bwd_data", m):
+        check(lib.dmn_field_bwd_data(ptr(g_raw), ptr(save), ptr(bwd_blob), m, ins_num, ptr(grec), current_stream()),
+              "dmn_field_bwd_data")
+    work = torch.empty(lib.dmn_field_wgrad_workspace_floats(ins_num, splits), dtype=torch.float32, device=dev)
+    grads = torch.zeros(n_params, dtype=torch.float32, device=dev)
+    with _timed("field_bwd_weights", m):
+        check(lib.dmn_field_bwd_weights(ptr(save), ptr(grec), m, ins_num, ptr(wgrad_idx), splits, ptr(work),
+                                        ptr(grads), 0, current_stream()), "dmn_field_bwd_weights")
+    return grads
+
+
 def field_embedded(embedded: torch.Tensor, blob: torch.Tensor, ins_num: int, precision: str = "fp32") -> torch.Tensor:
     _dev(embedded, "embedded")
     if embedded.shape[-1] != 90:

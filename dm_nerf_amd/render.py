@@ -8,7 +8,7 @@ from typing import Dict
 import torch
 
 from . import ops
-from .autograd import CompositeFn, FieldFn, needs_grad
+from .autograd import CompositeFn, field_fn, needs_grad
 from .dm_nerf import DM_NeRF, Embedder
 from .helpers import _unit_linspace
 
@@ -58,7 +58,7 @@ def dm_nerf(rays, position_embedder, view_embedder, model_coarse, model_fine, z_
 
     def field(model, z):
         if train:       # outputs carry grad to the parameters (SURVEY.md section 8b "Autograd")
-            return FieldFn.apply(rays_o, rays_d, z, model, precision, *model.parameters())
+            return field_fn().apply(rays_o, rays_d, z, model, precision, *model.parameters())
         return ops.field_rays(rays_o, rays_d, z, model.blob(precision), model.ins_num, precision)
 
     raw_coarse = field(model_coarse, z_vals_coarse)

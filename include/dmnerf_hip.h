@@ -100,6 +100,31 @@ int dmn_field_fwd_rays_x3(const float* rays_o, const float* rays_d, const float*
 int dmn_field_fwd_embedded_x3(const float* embedded, long n_points, const void* blob, int ins_num, int precision,
                               float* raw, int* status, void* stream);
 
+/* ---- training: backward of the field (autograd of networks/dm_nerf.py:80-106 inside train_dmsr.py:32-64) ----
+ * The forward writes a save record (register images per 32-point tile: encodings, every layer's output, ReLU
+ * sign bits), the backward-data call turns dL/d raw [M,C] into dL/d pre-activation of every layer (gradient
+ * record, same image layout; the instance branch stops at the trunk output, dm_nerf.py:95), and the
+ * weight-gradient call reduces gradient x input over the points into the flat parameter-gradient vector
+ * (state_dict order, dmn_field_param_floats entries).  All fp32 (exact MFMA).
+ *   dmn_field_save_floats / dmn_field_grad_floats: buffer sizes for n_points
+ *   dmn_field_bwd_blob_floats / dmn_field_bwd_pack_index: transposed-weight blob, packed with dmn_field_pack
+ *   dmn_field_wgrad_index_len / dmn_field_wgrad_index: scatter table (upload once per ins_num)
+ *   dmn_field_wgrad_workspace_floats: partial sums, `splits` slices of the points (a few per CU)        */
+long dmn_field_save_floats(long n_points);
+long dmn_field_grad_floats(long n_points, int ins_num);
+int dmn_field_fwd_rays_save(const float* rays_o, const float* rays_d, const float* z, long z_ray_stride, long n_rays,
+                            int n_samples, const float* blob, int ins_num, float* raw, float* save, void* stream);
+long dmn_field_bwd_blob_floats(int ins_num);
+int dmn_field_bwd_pack_index(int ins_num, int32_t* index_out);
+long dmn_field_wgrad_index_len(int ins_num);
+int dmn_field_wgrad_index(int ins_num, int32_t* index_out);
+int dmn_field_bwd_data(const float* g_raw, const float* save, const float* bwd_blob, long n_points, int ins_num,
+                       float* grad_record, void* stream);
+long dmn_field_wgrad_workspace_floats(int ins_num, int splits);
+int dmn_field_bwd_weights(const float* save, const float* grad_record, long n_points, int ins_num,
+                          const int32_t* wgrad_index, int splits, float* workspace, float* grads_flat,
+                          int accumulate, void* stream);
+
 /* ---- render_train (networks/render.py:6-28) / manipulator_render (manipulator.py:86-105) --
  * raw [N,S,C], z (stride), rays_d [N,3] -> rgb [N,3], weights [N,S], depth [N],
  * ins [N, C-5] (keep_last = 0, render_train drops the last channel, render.py:26) or

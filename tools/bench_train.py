@@ -30,6 +30,6 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for i in range(ns.steps):
     trainer.train_step(i + 1, rays, target, (pos, view, coarse, fine, args), z, opt)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / ns.steps
-print(json.dumps({"metric": "training rays/s (fwd HIP + HIP composite bwd + library-GEMM field bwd + Adam)",
+print(json.dumps({"metric": "training rays/s (HIP field fwd+save, HIP composite bwd, HIP field backward-data + weight-gradient kernels, Adam)",
                   "rays_per_step": ns.rays, "ms_per_step": dt * 1e3, "value": ns.rays / dt, "unit": "rays/s",
                   "precision_forward": ns.precision, "peak_mem_gb": torch.cuda.max_memory_allocated() / 2**30}))

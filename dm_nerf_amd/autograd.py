@@ -73,7 +73,8 @@ class FieldFn(torch.autograd.Function):
     def backward(ctx, g_raw):
         model = ctx.model
         n_params = sum(n for _, n, _ in ctx.meta)
-        flat = ops.field_backward(g_raw, ctx.save, model.blob("bwd"), model.ins_num, model.wgrad_index(), n_params)
+        flat = ops.field_backward(g_raw, ctx.save, model.blob("bwd"), model.ins_num, model.wgrad_index(), n_params,
+                                  wgrad_precision=WGRAD_PRECISION)
         ctx.save = None
         out: List = []
         at = 0
@@ -110,6 +111,7 @@ class FieldFnLibrary(torch.autograd.Function):
 
 
 FIELD_BACKWARD = "hip"          # "library": FieldFnLibrary
+WGRAD_PRECISION = "bf16x3"      # weight-gradient GEMMs: "bf16x3" (three bf16 MFMAs per product) or "fp32" (exact MFMA)
 
 
 def field_fn():

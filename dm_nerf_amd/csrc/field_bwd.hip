@@ -303,6 +303,121 @@ __global__ __launch_bounds__(256, 1) void field_wgrad_kernel(const WgArgs a) {
   }
 }
 
+// Same GEMMs on v_mfma_f32_32x32x16_bf16 with the split product G*X ~= Gh*Xh + Gh*Xl + Gl*Xh (bf16 keeps the fp32
+// exponent range, which gradients need; 2^-16 relative per product).  The [row][32 points] images are already in
+// operand order for this instruction (8 consecutive points per lane), so staging is conversion only: no transpose.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <int OT, int KT, int WR, int WC>
+__global__ __launch_bounds__(256, 1) void field_wgrad_x3_kernel(const WgArgs a) {
+  constexpr int R = 32 * (OT + KT);
+  constexpr int RB = 80;                   // bytes per LDS row: 32 bf16 + 16 pad (16-byte reads of 16 lanes hit 64 banks)
+  constexpr int NP = OT + KT;
+  constexpr int OTW = OT / WR, KTW = KT / WC;
+  static_assert(WR * WC == 4 && OTW * WR == OT && KTW * WC == KT && OTW * KTW <= 16, "wave grid");
+  __shared__ __attribute__((aligned(16))) char lds[2 * R * RB];   // hi plane, lo plane
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, l = lane & 31, kh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WC, wc = wave % WC;
+  const WGemm gm = a.gemm[a.list[blockIdx.y]];
+  const long per = (a.n_tiles + a.splits - 1) / a.splits;
+  const long t0 = (long)blockIdx.x * per;
+  const long t1 = t0 + per < a.n_tiles ? t0 + per : a.n_tiles;
+  float* const part = a.partial + (long)blockIdx.x * a.index_len;
+
+  f32x16 acc[OTW * KTW];
+#pragma unroll
+  for (int n = 0; n < OTW * KTW; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+  float bsum[OT];
+#pragma unroll
+  for (int i = 0; i < OT; ++i) bsum[i] = 0.f;
+
+  const int prow = tid >> 3, ppc = tid & 7;
+  f32x4 stg[NP];
+  auto fetch = [&](long tile) {
+    const float* gsrc = a.grad + tile * a.grad_tile_floats + gm.g_reg * 64 + tid * 4;
+    const float* xsrc = a.save + tile * kSaveTileFloats + gm.x_reg * 64 + tid * 4;
+#pragma unroll
+    for (int it = 0; it < OT; ++it) stg[it] = *reinterpret_cast<const f32x4*>(gsrc + it * 1024);
+#pragma unroll
+    for (int it = 0; it < KT; ++it) stg[OT + it] = *reinterpret_cast<const f32x4*>(xsrc + it * 1024);
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+      const f32x4 v = stg[it];
+      bf16x4 hi, lo;
+      hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
+      lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
+      lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
+      char* d = lds + (it * 32 + prow) * RB + ppc * 8;
+      *reinterpret_cast<bf16x4*>(d) = hi;
+      *reinterpret_cast<bf16x4*>(d + R * RB) = lo;
+      if (it < OT) bsum[it < OT ? it : 0] += (v.x + v.y) + (v.z + v.w);
+    }
+  };
+
+  if (t0 < t1) fetch(t0);
+  for (long t = t0; t < t1; ++t) {
+    __syncthreads();                       // everybody is done reading the previous tile
+    stage();
+    __syncthreads();
+    if (t + 1 < t1) fetch(t + 1);          // in flight under this tile's MFMAs
+    const char* pa = lds + (wr * OTW * 32 + l) * RB + kh * 16;
+    const char* pb = lds + (OT * 32 + wc * KTW * 32 + l) * RB + kh * 16;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 ah[OTW], al[OTW], bh[KTW], bl[KTW];
+#pragma unroll
+      for (int i = 0; i < OTW; ++i) {
+        ah[i] = *reinterpret_cast<const bf16x8*>(pa + i * 32 * RB + ks * 32);
+        al[i] = *reinterpret_cast<const bf16x8*>(pa + i * 32 * RB + ks * 32 + R * RB);
+      }
+#pragma unroll
+      for (int j = 0; j < KTW; ++j) {
+        bh[j] = *reinterpret_cast<const bf16x8*>(pb + j * 32 * RB + ks * 32);
+        bl[j] = *reinterpret_cast<const bf16x8*>(pb + j * 32 * RB + ks * 32 + R * RB);
+      }
+#pragma unroll
+      for (int i = 0; i < OTW; ++i)
+#pragma unroll
+        for (int j = 0; j < KTW; ++j) {
+          f32x16 c = acc[i * KTW + j];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], c, 0, 0, 0);
+          acc[i * KTW + j] = c;
+        }
+    }
+  }
+
+  constexpr int K = KT * 32;
+#pragma unroll
+  for (int i = 0; i < OTW; ++i)
+#pragma unroll
+    for (int j = 0; j < KTW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = (wr * OTW + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int k = (wc * KTW + j) * 32 + l;
+        part[gm.index_off + o * K + k] = acc[i * KTW + j][r];
+      }
+  if (gm.bias_off >= 0) {
+#pragma unroll
+    for (int it = 0; it < OT; ++it) {
+      float v = bsum[it];
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      v += __shfl_xor(v, 4);
+      if (ppc == 0) part[gm.bias_off + it * 32 + prow] = v;
+    }
+  }
+}
+
 __global__ void field_wgrad_reduce_kernel(const float* partial, const int32_t* index, long index_len, int splits,
                                           float* grads, int accumulate) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -315,9 +430,12 @@ __global__ void field_wgrad_reduce_kernel(const float* partial, const int32_t* i
 }
 
 template <int OT, int KT, int WR, int WC>
-void launch_class(WgArgs& a, const int* ids, int n, hipStream_t st) {
+void launch_class(WgArgs& a, const int* ids, int n, bool x3, hipStream_t st) {
   for (int i = 0; i < n; ++i) a.list[i] = ids[i];
-  hipLaunchKernelGGL((field_wgrad_kernel<OT, KT, WR, WC>), dim3(a.splits, n), dim3(256), 0, st, a);
+  if (x3)
+    hipLaunchKernelGGL((field_wgrad_x3_kernel<OT, KT, WR, WC>), dim3(a.splits, n), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((field_wgrad_kernel<OT, KT, WR, WC>), dim3(a.splits, n), dim3(256), 0, st, a);
 }
 
 }  // namespace
@@ -354,9 +472,11 @@ extern "C" long dmn_field_wgrad_workspace_floats(int ins_num, int splits) {
 }
 
 extern "C" int dmn_field_bwd_weights(const float* save, const float* grad_record, long n_points, int ins_num,
-                                     const int32_t* wgrad_index, int splits, float* workspace, float* grads_flat,
-                                     int accumulate, void* stream) {
+                                     const int32_t* wgrad_index, int splits, int precision, float* workspace,
+                                     float* grads_flat, int accumulate, void* stream) {
   if (n_points < 0 || ins_num < 0 || splits <= 0 || splits > 65535) return DMN_ERR_BAD_ARG;
+  if (precision != DMN_PREC_FP32 && precision != DMN_PREC_BF16X3) return DMN_ERR_BAD_ARG;   // fp16 underflows on gradients
+  const bool x3 = precision == DMN_PREC_BF16X3;
   if (n_points == 0) return DMN_OK;
   if (!save || !grad_record || !wgrad_index || !workspace || !grads_flat) return DMN_ERR_BAD_ARG;
   const int T = ins_tiles(ins_num);
@@ -373,23 +493,23 @@ extern "C" int dmn_field_bwd_weights(const float* save, const float* grad_record
   wgemm_table(T, a.gemm);
   {
     const int big[] = {1, 2, 3, 4, 5, 7, 8, 9, 10};
-    launch_class<8, 8, 2, 2>(a, big, 9, st);
+    launch_class<8, 8, 2, 2>(a, big, 9, x3, st);
     const int pe[] = {0, 6};
-    launch_class<8, 2, 4, 1>(a, pe, 2, st);
+    launch_class<8, 2, 4, 1>(a, pe, 2, x3, st);
     const int half[] = {11, 13};
-    launch_class<4, 8, 2, 2>(a, half, 2, st);
+    launch_class<4, 8, 2, 2>(a, half, 2, x3, st);
     const int view[] = {12};
-    launch_class<4, 1, 4, 1>(a, view, 1, st);
+    launch_class<4, 1, 4, 1>(a, view, 1, x3, st);
     const int rgbo[] = {15};
-    launch_class<1, 4, 1, 4>(a, rgbo, 1, st);
+    launch_class<1, 4, 1, 4>(a, rgbo, 1, x3, st);
     const int dens[] = {16};
-    launch_class<1, 8, 1, 4>(a, dens, 1, st);
+    launch_class<1, 8, 1, 4>(a, dens, 1, x3, st);
     const int inso[] = {14};
     switch (T) {
-      case 1: launch_class<1, 4, 1, 4>(a, inso, 1, st); break;
-      case 2: launch_class<2, 4, 2, 2>(a, inso, 1, st); break;
-      case 3: launch_class<3, 4, 1, 4>(a, inso, 1, st); break;
-      case 4: launch_class<4, 4, 2, 2>(a, inso, 1, st); break;
+      case 1: launch_class<1, 4, 1, 4>(a, inso, 1, x3, st); break;
+      case 2: launch_class<2, 4, 2, 2>(a, inso, 1, x3, st); break;
+      case 3: launch_class<3, 4, 1, 4>(a, inso, 1, x3, st); break;
+      case 4: launch_class<4, 4, 2, 2>(a, inso, 1, x3, st); break;
     }
   }
   const long n = a.index_len;

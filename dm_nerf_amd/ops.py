@@ -250,8 +250,12 @@ def field_rays_save(rays_o: torch.Tensor, rays_d: torch.Tensor, z: torch.Tensor,
 
 
 def field_backward(g_raw: torch.Tensor, save: torch.Tensor, bwd_blob: torch.Tensor, ins_num: int,
-                   wgrad_idx: torch.Tensor, n_params: int, splits: Optional[int] = None) -> torch.Tensor:
-    """dL/d raw [N,S,C] + save record -> flat parameter gradient (state_dict order)."""
+                   wgrad_idx: torch.Tensor, n_params: int, splits: Optional[int] = None,
+                   wgrad_precision: str = "bf16x3") -> torch.Tensor:
+    """dL/d raw [N,S,C] + save record -> flat parameter gradient (state_dict order).  ``wgrad_precision``:
+    arithmetic of the weight-gradient GEMMs, "fp32" (exact MFMA) or "bf16x3" (three bf16 MFMAs per product)."""
+    if wgrad_precision not in ("fp32", "bf16x3"):
+        raise ValueError("wgrad_precision must be 'fp32' or 'bf16x3' (gradients underflow fp16)")
     _dev(g_raw, "g_raw")
     g_raw = g_raw.contiguous()
     m = g_raw.shape[0] * g_raw.shape[1]
@@ -271,8 +275,9 @@ def field_backward(g_raw: torch.Tensor, save: torch.Tensor, bwd_blob: torch.Tens
     work = torch.empty(lib.dmn_field_wgrad_workspace_floats(ins_num, splits), dtype=torch.float32, device=dev)
     grads = torch.zeros(n_params, dtype=torch.float32, device=dev)
     with _timed("field_bwd_weights", m):
-        check(lib.dmn_field_bwd_weights(ptr(save), ptr(grec), m, ins_num, ptr(wgrad_idx), splits, ptr(work),
-                                        ptr(grads), 0, current_stream()), "dmn_field_bwd_weights")
+        check(lib.dmn_field_bwd_weights(ptr(save), ptr(grec), m, ins_num, ptr(wgrad_idx), splits,
+                                        precision_code(wgrad_precision), ptr(work), ptr(grads), 0,
+                                        current_stream()), "dmn_field_bwd_weights")
     return grads
 
 

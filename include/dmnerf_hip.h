@@ -105,7 +105,9 @@ int dmn_field_fwd_embedded_x3(const float* embedded, long n_points, const void* 
  * sign bits), the backward-data call turns dL/d raw [M,C] into dL/d pre-activation of every layer (gradient
  * record, same image layout; the instance branch stops at the trunk output, dm_nerf.py:95), and the
  * weight-gradient call reduces gradient x input over the points into the flat parameter-gradient vector
- * (state_dict order, dmn_field_param_floats entries).  All fp32 (exact MFMA).
+ * (state_dict order, dmn_field_param_floats entries).  Forward and backward-data are exact fp32 MFMA; the
+ * weight-gradient GEMMs run in DMN_PREC_FP32 or DMN_PREC_BF16X3 (three bf16 MFMAs per product, fp32 accumulate;
+ * DMN_PREC_FP16X3 is refused: gradients underflow fp16).
  *   dmn_field_save_floats / dmn_field_grad_floats: buffer sizes for n_points
  *   dmn_field_bwd_blob_floats / dmn_field_bwd_pack_index: transposed-weight blob, packed with dmn_field_pack
  *   dmn_field_wgrad_index_len / dmn_field_wgrad_index: scatter table (upload once per ins_num)
@@ -122,8 +124,8 @@ int dmn_field_bwd_data(const float* g_raw, const float* save, const float* bwd_b
                        float* grad_record, void* stream);
 long dmn_field_wgrad_workspace_floats(int ins_num, int splits);
 int dmn_field_bwd_weights(const float* save, const float* grad_record, long n_points, int ins_num,
-                          const int32_t* wgrad_index, int splits, float* workspace, float* grads_flat,
-                          int accumulate, void* stream);
+                          const int32_t* wgrad_index, int splits, int precision, float* workspace,
+                          float* grads_flat, int accumulate, void* stream);
 
 /* ---- render_train (networks/render.py:6-28) / manipulator_render (manipulator.py:86-105) --
  * raw [N,S,C], z (stride), rays_d [N,3] -> rgb [N,3], weights [N,S], depth [N],

@@ -612,11 +612,14 @@ def _min_abs_preactivation(net, o, d, z):
     return low.reshape(z.shape)
 
 
+@pytest.mark.parametrize("wgrad", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("ins_num,n,s", [(13, 37, 64), (93, 11, 100), (40, 5, 192), (13, 700, 64)])
-def test_field_backward_kernels_match_library_gemm_backward(ins_num, n, s):
+def test_field_backward_kernels_match_library_gemm_backward(ins_num, n, s, wgrad, monkeypatch):
     """HIP backward (save record -> backward-data kernel -> split-K weight-gradient kernel) against autograd
     through library GEMMs on the device, every parameter of the network, ragged point counts, 1..3 logit tiles."""
+    from dm_nerf_amd import autograd
     from dm_nerf_amd.autograd import FieldFn, FieldFnLibrary
+    monkeypatch.setattr(autograd, "WGRAD_PRECISION", wgrad)
     _, _, net, _, _ = nets(ins_num, 3, 4)
     rng = np.random.default_rng(900 + ins_num + n)
     o, d, _, _ = cases.path_rays(n, seed=31 + n)
@@ -642,7 +645,7 @@ def test_field_backward_kernels_match_library_gemm_backward(ins_num, n, s):
         err = rel_err(grads["hip"][k], grads["lib"][k])
         worst = max(worst, err)
         assert err < 1e-4, (k, err)
-    print(f"ins_num={ins_num} M={n * s}: worst rel err vs library backward {worst:.2e}")
+    print(f"ins_num={ins_num} M={n * s} wgrad={wgrad}: worst rel err vs library backward {worst:.2e}")
 
 
 def test_field_backward_respects_detach_and_frozen_parameters():

@@ -182,10 +182,11 @@ __global__ __launch_bounds__(256, 1) void field_bwd_data_kernel(const BwdArgs a)
 struct WgArgs {
   const float* save;
   const float* grad;
-  float* partial;          // [splits][index_len]
+  float* partial;          // this class's region: [splits][slice_len], element e at e - elem_base
   long n_tiles;            // 32-point tiles
   long grad_tile_floats;
-  long index_len;
+  long slice_len, elem_base;
+  long elem_base_small_len;   // slice length of the small-GEMM region
   int splits;
   WGemm gemm[kWGemms];
   int list[kWGemms];       // blockIdx.y -> gemm id (GEMMs of one shape class per launch)
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256, 1) void field_wgrad_kernel(const WgArgs a) {
   const long per = (a.n_tiles + a.splits - 1) / a.splits;
   const long t0 = (long)blockIdx.x * per;
   const long t1 = t0 + per < a.n_tiles ? t0 + per : a.n_tiles;
-  float* const part = a.partial + (long)blockIdx.x * a.index_len;
+  float* const part = a.partial + (long)blockIdx.x * a.slice_len - a.elem_base;
 
   f32x16 acc[OTW * KTW];
 #pragma unroll
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(256, 1) void field_wgrad_x3_kernel(const WgArgs a) 
   const long per = (a.n_tiles + a.splits - 1) / a.splits;
   const long t0 = (long)blockIdx.x * per;
   const long t1 = t0 + per < a.n_tiles ? t0 + per : a.n_tiles;
-  float* const part = a.partial + (long)blockIdx.x * a.index_len;
+  float* const part = a.partial + (long)blockIdx.x * a.slice_len - a.elem_base;
 
   f32x16 acc[OTW * KTW];
 #pragma unroll
@@ -424,14 +425,24 @@ __global__ void field_wgrad_reduce_kernel(const float* partial, const int32_t* i
   if (e >= index_len) return;
   const int dst = index[e];
   if (dst < 0) return;
+  const bool big = e < kWgradBigLen;
+  const long len = big ? kWgradBigLen : index_len - kWgradBigLen;
+  const float* p = big ? partial + e : partial + (long)splits * kWgradBigLen + (e - kWgradBigLen);
+  const int n = big ? splits : splits * kWgradSmallSplitFactor;
   float v = 0.f;
-  for (int s = 0; s < splits; ++s) v += partial[(long)s * index_len + e];
+  for (int s = 0; s < n; ++s) v += p[(long)s * len];
   grads[dst] = accumulate ? grads[dst] + v : v;
 }
 
 template <int OT, int KT, int WR, int WC>
-void launch_class(WgArgs& a, const int* ids, int n, bool x3, hipStream_t st) {
+void launch_class(WgArgs a, const int* ids, int n, bool x3, hipStream_t st) {
   for (int i = 0; i < n; ++i) a.list[i] = ids[i];
+  if (!(OT == 8 && KT == 8)) {             // small GEMMs: more, shorter point slices in their own workspace region
+    a.partial += (long)a.splits * kWgradBigLen;
+    a.slice_len = a.elem_base_small_len;
+    a.elem_base = kWgradBigLen;
+    a.splits *= kWgradSmallSplitFactor;
+  }
   if (x3)
     hipLaunchKernelGGL((field_wgrad_x3_kernel<OT, KT, WR, WC>), dim3(a.splits, n), dim3(256), 0, st, a);
   else
@@ -468,7 +479,8 @@ extern "C" int dmn_field_bwd_data(const float* g_raw, const float* save, const f
 
 extern "C" long dmn_field_wgrad_workspace_floats(int ins_num, int splits) {
   if (ins_num < 0 || ins_tiles(ins_num) > kMaxInsTiles || splits <= 0) return DMN_ERR_BAD_ARG;
-  return (long)splits * wgrad_index_len(ins_tiles(ins_num));
+  const long small = wgrad_index_len(ins_tiles(ins_num)) - kWgradBigLen;
+  return (long)splits * (kWgradBigLen + kWgradSmallSplitFactor * small);
 }
 
 extern "C" int dmn_field_bwd_weights(const float* save, const float* grad_record, long n_points, int ins_num,
@@ -488,7 +500,9 @@ extern "C" int dmn_field_bwd_weights(const float* save, const float* grad_record
   a.partial = workspace;
   a.n_tiles = ((n_points + 127) / 128) * 4;
   a.grad_tile_floats = grad_tile_floats(T);
-  a.index_len = wgrad_index_len(T);
+  a.slice_len = kWgradBigLen;
+  a.elem_base = 0;
+  a.elem_base_small_len = wgrad_index_len(T) - kWgradBigLen;
   a.splits = splits;
   wgemm_table(T, a.gemm);
   {
@@ -512,7 +526,7 @@ extern "C" int dmn_field_bwd_weights(const float* save, const float* grad_record
       case 4: launch_class<4, 4, 2, 2>(a, inso, 1, x3, st); break;
     }
   }
-  const long n = a.index_len;
+  const long n = wgrad_index_len(T);
   hipLaunchKernelGGL(field_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace,
                      wgrad_index, n, splits, grads_flat, accumulate);
   return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;

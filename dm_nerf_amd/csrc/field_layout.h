@@ -219,6 +219,9 @@ struct WGemm {
   int bias_off;            // offset of its [g_tiles*32] bias scatter table, or -1
 };
 constexpr int kWGemms = 17;
+DMN_HD constexpr bool wgemm_big(const WGemm& g) { return g.g_tiles == 8 && g.x_tiles == 8; }
+constexpr long kWgradBigLen = 9L * (256 * 256 + 256);      // the nine 256x256 GEMMs and their biases come first
+constexpr int kWgradSmallSplitFactor = 3;                  // the small GEMMs are cut into 3x as many point slices
 // The list (index_off / bias_off are running sums in list order; bias only where a layer's G appears first).
 inline void wgemm_table(int T, WGemm* g) {
   int n = 0;
@@ -239,10 +242,15 @@ inline void wgemm_table(int T, WGemm* g) {
   add(kGradHead, T, kSaveI1, 4, true);                                     // 14 ins_linear
   add(kGradHead + 16 * T, 1, kSaveR1, 4, true);                            // 15 rgb_linear (rows rgb0..2)
   add(kGradHead + 16 * T, 1, save_h(8), 8, true);                          // 16 density_linear (row sigma)
+  // scatter-table / partial-sum element space: [tables of the 8x8 GEMMs][their biases][other tables][other biases];
+  // the two regions are reduced over different numbers of point slices (wgrad_big_len)
   int off = 0;
-  for (int i = 0; i < kWGemms; ++i) { g[i].index_off = off; off += g[i].g_tiles * 32 * g[i].x_tiles * 32; }
-  for (int i = 0; i < kWGemms; ++i)
-    if (g[i].bias_off == 0) { g[i].bias_off = off; off += g[i].g_tiles * 32; }
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int i = 0; i < kWGemms; ++i)
+      if (wgemm_big(g[i]) == (pass == 0)) { g[i].index_off = off; off += g[i].g_tiles * 32 * g[i].x_tiles * 32; }
+    for (int i = 0; i < kWGemms; ++i)
+      if (wgemm_big(g[i]) == (pass == 0) && g[i].bias_off == 0) { g[i].bias_off = off; off += g[i].g_tiles * 32; }
+  }
 }
 inline long wgrad_index_len(int T) {
   WGemm g[kWGemms];

@@ -46,6 +46,7 @@ SIGNATURES = {
     "dmn_field_save_floats": (c_long, [c_long]),
     "dmn_field_grad_floats": (c_long, [c_long, c_int]),
     "dmn_field_fwd_rays_save": (c_int, [_P, _P, _P, c_long, c_long, c_int, _P, c_int, _P, _P, _P]),
+    "dmn_field_fwd_rays_x3_save": (c_int, [_P, _P, _P, c_long, c_long, c_int, _P, c_int, c_int, _P, _P, _P]),
     "dmn_field_bwd_blob_floats": (c_long, [c_int]),
     "dmn_field_bwd_pack_index": (c_int, [c_int, _P]),
     "dmn_field_wgrad_index_len": (c_long, [c_int]),

@@ -6,7 +6,8 @@ Forward of both functions is the hand-written HIP kernel.  Backward:
   (the instance map is composited with ``weights.detach()``, networks/render.py:22-23).
 * ``FieldFn``: hand-written HIP kernels (``csrc/field_bwd.hip``): the forward writes a save record, a fused
   backward-data kernel chains dL/d pre-activation through the layers in registers, a split-K MFMA kernel reduces
-  the 30 weight/bias gradients over all sample points.  Under autograd the field always runs in exact fp32.
+  the 30 weight/bias gradients over all sample points.  ``args.precision`` selects the forward under autograd:
+  exact fp32, or three bf16 MFMAs per product for "bf16x3" / "fp16x3".
   ``FieldFnLibrary`` (library GEMMs on recomputed activations, ``torch_field_on_rays``) is the cross-check.
   Nothing here runs on the CPU.
 
@@ -64,7 +65,9 @@ class FieldFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rays_o, rays_d, z, model, precision, *params):
-        raw, save = ops.field_rays_save(rays_o, rays_d, z, model.blob("fp32"), model.ins_num)
+        # "fp16x3" trains in bf16x3: fp16 needs its range flag read back between forward and backward
+        fwd = "fp32" if precision == "fp32" else "bf16x3"
+        raw, save = ops.field_rays_save(rays_o, rays_d, z, model.blob(fwd), model.ins_num, fwd)
         ctx.save, ctx.model = save, model
         ctx.meta = [(p.shape, p.numel(), p.requires_grad) for p in params]
         return raw

@@ -126,11 +126,22 @@ struct EpiSplit {
   float* sigma;          // density accumulation (only when dens)
   const float* dw;       // density weights of this lane-half
   bool dens;
+  float* img = nullptr;  // training: register image of this layer's output (field_layout.h), lane offset included
+  unsigned* msk = nullptr;   // training: sign bits of the ReLU layer, 32 registers per word
   __device__ __forceinline__ void operator()(int t, int q, const f32x16& acc) const {
     float x0 = acc[2 * q], x1 = acc[2 * q + 1];
     if (RELU) {                              // v_med3_f32: one instruction, no canonicalising pre-max
       x0 = __builtin_amdgcn_fmed3f(x0, 0.f, __builtin_inff());
       x1 = __builtin_amdgcn_fmed3f(x1, 0.f, __builtin_inff());
+    }
+    if (img != nullptr) {
+      img[(16 * t + 2 * q) * 64] = x0;
+      img[(16 * t + 2 * q + 1) * 64] = x1;
+      if (RELU) {
+        unsigned& w = msk[(16 * t + 2 * q) >> 5];
+        w |= (x0 > 0.f ? 1u : 0u) << ((16 * t + 2 * q) & 31);
+        w |= (x1 > 0.f ? 1u : 0u) << ((16 * t + 2 * q + 1) & 31);
+      }
     }
     if (dens) *sigma = fmaf(x1, dw[16 * t + 2 * q + 1], fmaf(x0, dw[16 * t + 2 * q], *sigma));
     if (P::kCheckRange) {
@@ -146,8 +157,17 @@ struct EpiSplit {
 struct EpiRgb {
   float* rgb;            // [3] partial sums of this lane-half
   const float* rw;       // cst + kConstRgbW + h*64
+  float* img = nullptr;  // training: image of the post-ReLU layer output, and its sign bits
+  unsigned* msk = nullptr;
   __device__ __forceinline__ void operator()(int t, int q, const f32x16& acc) const {
     const float x0 = fmaxf(acc[2 * q], 0.f), x1 = fmaxf(acc[2 * q + 1], 0.f);
+    if (img != nullptr) {
+      img[(16 * t + 2 * q) * 64] = x0;
+      img[(16 * t + 2 * q + 1) * 64] = x1;
+      unsigned& w = msk[(16 * t + 2 * q) >> 5];
+      w |= (x0 > 0.f ? 1u : 0u) << ((16 * t + 2 * q) & 31);
+      w |= (x1 > 0.f ? 1u : 0u) << ((16 * t + 2 * q + 1) & 31);
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c)
       rgb[c] = fmaf(x1, rw[c * 128 + 16 * t + 2 * q + 1], fmaf(x0, rw[c * 128 + 16 * t + 2 * q], rgb[c]));
@@ -166,6 +186,16 @@ struct EpiStore {
     }
   }
 };
+
+// training: write and clear the sign-bit words a ReLU layer's epilogues collected
+template <int N>
+__device__ __forceinline__ void flush_mask(float* dst, unsigned* msk) {
+#pragma unroll
+  for (int w = 0; w < N; ++w) {
+    dst[w * 64] = __uint_as_float(msk[w]);
+    msk[w] = 0u;
+  }
+}
 
 // One layer: NT output tiles x (NKS + NKX) k-steps of 16; xh/xl: main operand fragments,
 // eh/el: extra fragments (position / direction encodings) appended to the k range.
@@ -224,7 +254,7 @@ __device__ __forceinline__ void layer_x3(Ctx& c, const float* bias, const typena
   for (int q = 0; q < 8; ++q) epi(NT - 1, q, acc[(NT - 1) & 1]);
 }
 
-template <class P, int T>
+template <class P, int T, bool SAVE>
 __global__ __launch_bounds__(256, 1) void field_fwd_x3_kernel(const FieldArgs a) {
   typedef typename P::frag frag;
   __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
@@ -247,10 +277,19 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x3_kernel(const FieldArgs a)
   const bool valid = m < a.M;
   const long mc = valid ? m : a.M - 1;
   float amax = 0.f;
+  // training: this wave's save record, lane offset included (null otherwise)
+  float* const rec = SAVE ? a.save + ((long)blockIdx.x * 4 + wave_s) * kSaveTileFloats + lane : nullptr;
+  unsigned msk[4] = {0u, 0u, 0u, 0u};
   frag pe_h[4], pe_l[4], qe_h[2], qe_l[2];
   {
     float pe[32], qe[16];
     point_encodings(a, mc, h, pe, qe);
+    if (SAVE) {
+#pragma unroll
+      for (int j = 0; j < 32; ++j) rec[(kSavePe + j) * 64] = pe[j];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) rec[(kSaveQe + j) * 64] = qe[j];
+    }
 #pragma unroll
     for (int j = 0; j < 32; j += 2) {
       if (P::kCheckRange) amax = fmaxf(amax, fmaxf(fabsf(pe[j]), fabsf(pe[j + 1])));
@@ -268,20 +307,25 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x3_kernel(const FieldArgs a)
 
   // ---- mlps.0: position encoding (4 k-steps) -> act
   layer_x3<P, 8, 4, 0>(c, cst + kConstBias8 + h * 128, pe_h, pe_l, pe_h, pe_l,
-                       Relu{act_h, act_l, &amax, &sigma, dw, false});
+                       Relu{act_h, act_l, &amax, &sigma, dw, false, SAVE ? rec + save_h(1) * 64 : nullptr, msk});
+  if (SAVE) flush_mask<4>(rec + save_mask(1) * 64, msk);
   // ---- mlps.1 .. mlps.7 in ping-pong pairs; mlps.5 (skip connection) also consumes the position encoding
   int l = 1;
 #pragma unroll 1
   for (int it = 0; it < 3; ++it) {
     layer_x3<P, 8, 16, 0>(c, cst + kConstBias8 + l * 256 + h * 128, act_h, act_l, pe_h, pe_l,
-                          Relu{nxt_h, nxt_l, &amax, &sigma, dw, false});
+                          Relu{nxt_h, nxt_l, &amax, &sigma, dw, false, SAVE ? rec + (save_h(1) + 128 * l) * 64 : nullptr, msk});
+    if (SAVE) flush_mask<4>(rec + (save_mask(1) + 4 * l) * 64, msk);
     ++l;
     layer_x3<P, 8, 16, 0>(c, cst + kConstBias8 + l * 256 + h * 128, nxt_h, nxt_l, pe_h, pe_l,
-                          Relu{act_h, act_l, &amax, &sigma, dw, l == kDepth - 1});   // density from mlps.7 output
+                          Relu{act_h, act_l, &amax, &sigma, dw, l == kDepth - 1,    // density from mlps.7 output
+                               SAVE ? rec + (save_h(1) + 128 * l) * 64 : nullptr, msk});
+    if (SAVE) flush_mask<4>(rec + (save_mask(1) + 4 * l) * 64, msk);
     ++l;
     if (it == 1) {
       layer_x3<P, 8, 16, 4>(c, cst + kConstBias8 + l * 256 + h * 128, act_h, act_l, pe_h, pe_l,
-                            Relu{nxt_h, nxt_l, &amax, &sigma, dw, false});
+                            Relu{nxt_h, nxt_l, &amax, &sigma, dw, false, SAVE ? rec + (save_h(1) + 128 * l) * 64 : nullptr, msk});
+      if (SAVE) flush_mask<4>(rec + (save_mask(1) + 4 * l) * 64, msk);
       ++l;
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
@@ -296,9 +340,11 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x3_kernel(const FieldArgs a)
 
   // ---- rgb_feature_linear (no activation) -> nxt; rgb_feature_linears.0 on [feature, dirs] -> rgb_linear
   layer_x3<P, 8, 16, 0>(c, cst + kConstBias8 + 8 * 256 + h * 128, act_h, act_l, pe_h, pe_l,
-                        Lin{nxt_h, nxt_l, &amax, &sigma, dw, false});
+                        Lin{nxt_h, nxt_l, &amax, &sigma, dw, false, SAVE ? rec + kSaveFeat * 64 : nullptr, msk});
   float rgb[3] = {0.f, 0.f, 0.f};
-  layer_x3<P, 4, 16, 2>(c, cst + kConstBias4 + h * 64, nxt_h, nxt_l, qe_h, qe_l, EpiRgb{rgb, cst + kConstRgbW + h * 64});
+  layer_x3<P, 4, 16, 2>(c, cst + kConstBias4 + h * 64, nxt_h, nxt_l, qe_h, qe_l,
+                        EpiRgb{rgb, cst + kConstRgbW + h * 64, SAVE ? rec + kSaveR1 * 64 : nullptr, msk});
+  if (SAVE) flush_mask<2>(rec + kSaveMaskR1 * 64, msk);
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     rgb[k] += __shfl_xor(rgb[k], 32);
@@ -314,9 +360,10 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x3_kernel(const FieldArgs a)
 
   // ---- ins_feature_linear on the trunk output (no activation) -> nxt; ins_feature_linears.0 (ReLU) -> act[0..7]
   layer_x3<P, 8, 16, 0>(c, cst + kConstBias8 + 9 * 256 + h * 128, act_h, act_l, pe_h, pe_l,
-                        Lin{nxt_h, nxt_l, &amax, &sigma, dw, false});
+                        Lin{nxt_h, nxt_l, &amax, &sigma, dw, false, SAVE ? rec + kSaveInsF * 64 : nullptr, msk});
   layer_x3<P, 4, 16, 0>(c, cst + kConstBias4 + 128 + h * 64, nxt_h, nxt_l, pe_h, pe_l,
-                        Relu{act_h, act_l, &amax, &sigma, dw, false});
+                        Relu{act_h, act_l, &amax, &sigma, dw, false, SAVE ? rec + kSaveI1 * 64 : nullptr, msk});
+  if (SAVE) flush_mask<2>(rec + kSaveMaskI1 * 64, msk);
   // ---- ins_linear: 128 -> ins_num + 1, T tiles, stored straight from the accumulators
   layer_x3<P, T, 8, 0>(c, cst + kConstBiasO + h * 64, act_h, act_l, pe_h, pe_l, EpiStore{out, a.ins_ch, h});
 
@@ -338,17 +385,17 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x3_kernel(const FieldArgs a)
 #endif
 }
 
-template <class P>
+template <class P, bool SAVE>
 int launch_x3(const FieldArgs& a, int ins_num, hipStream_t st) {
   if (a.M <= 0) return DMN_OK;
   const long blocks = (a.M + 127) / 128;
   if (blocks > 0x7fffffffL) return DMN_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)blocks), block(256);
   switch (ins_tiles(ins_num)) {
-    case 1: hipLaunchKernelGGL((field_fwd_x3_kernel<P, 1>), grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL((field_fwd_x3_kernel<P, 2>), grid, block, 0, st, a); break;
-    case 3: hipLaunchKernelGGL((field_fwd_x3_kernel<P, 3>), grid, block, 0, st, a); break;
-    case 4: hipLaunchKernelGGL((field_fwd_x3_kernel<P, 4>), grid, block, 0, st, a); break;
+    case 1: hipLaunchKernelGGL((field_fwd_x3_kernel<P, 1, SAVE>), grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL((field_fwd_x3_kernel<P, 2, SAVE>), grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL((field_fwd_x3_kernel<P, 3, SAVE>), grid, block, 0, st, a); break;
+    case 4: hipLaunchKernelGGL((field_fwd_x3_kernel<P, 4, SAVE>), grid, block, 0, st, a); break;
     default: return DMN_ERR_UNSUPPORTED;
   }
   return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
@@ -356,8 +403,10 @@ int launch_x3(const FieldArgs& a, int ins_num, hipStream_t st) {
 
 int launch_prec(const FieldArgs& a, int ins_num, int precision, hipStream_t st) {
   if (ins_num < 0 || ins_tiles(ins_num) > kMaxInsTiles) return DMN_ERR_UNSUPPORTED;
-  if (precision == DMN_PREC_FP16X3) return launch_x3<PrecF16>(a, ins_num, st);
-  if (precision == DMN_PREC_BF16X3) return launch_x3<PrecBF16>(a, ins_num, st);
+  if (a.save != nullptr)      // training: bf16 only (no range guard to consult between forward and backward)
+    return precision == DMN_PREC_BF16X3 ? launch_x3<PrecBF16, true>(a, ins_num, st) : DMN_ERR_BAD_ARG;
+  if (precision == DMN_PREC_FP16X3) return launch_x3<PrecF16, false>(a, ins_num, st);
+  if (precision == DMN_PREC_BF16X3) return launch_x3<PrecBF16, false>(a, ins_num, st);
   return DMN_ERR_BAD_ARG;
 }
 
@@ -401,7 +450,18 @@ extern "C" int dmn_field_fwd_rays_x3(const float* rays_o, const float* rays_d, c
   if (n_rays == 0) return DMN_OK;
   if (!rays_o || !rays_d || !z || !blob || !raw) return DMN_ERR_BAD_ARG;
   FieldArgs a{rays_o, rays_d, z, z_ray_stride, nullptr, blob, raw, status, n_rays * (long)n_samples, n_samples,
-              ins_num + 1};
+              ins_num + 1, nullptr};
+  return launch_prec(a, ins_num, precision, (hipStream_t)stream);
+}
+
+extern "C" int dmn_field_fwd_rays_x3_save(const float* rays_o, const float* rays_d, const float* z, long z_ray_stride,
+                                          long n_rays, int n_samples, const void* blob, int ins_num, int precision,
+                                          float* raw, float* save, void* stream) {
+  if (n_rays < 0 || n_samples <= 0 || ins_num < 0 || z_ray_stride < 0) return DMN_ERR_BAD_ARG;
+  if (n_rays == 0) return DMN_OK;
+  if (!rays_o || !rays_d || !z || !blob || !raw || !save) return DMN_ERR_BAD_ARG;
+  FieldArgs a{rays_o, rays_d, z, z_ray_stride, nullptr, blob, raw, nullptr, n_rays * (long)n_samples, n_samples,
+              ins_num + 1, save};
   return launch_prec(a, ins_num, precision, (hipStream_t)stream);
 }
 

@@ -234,8 +234,11 @@ def wgrad_index(ins_num: int, device) -> torch.Tensor:
 
 
 def field_rays_save(rays_o: torch.Tensor, rays_d: torch.Tensor, z: torch.Tensor, blob: torch.Tensor,
-                    ins_num: int) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Exact-fp32 field forward that also writes the save record the backward kernels read."""
+                    ins_num: int, precision: str = "fp32") -> Tuple[torch.Tensor, torch.Tensor]:
+    """Field forward that also writes the save record the backward kernels read: exact fp32 ("fp32") or three bf16
+    MFMAs per product ("bf16x3", with the x3 blob of that precision)."""
+    if precision not in ("fp32", "bf16x3"):
+        raise ValueError("the saving forward runs in 'fp32' or 'bf16x3'")
     n = rays_o.shape[0]
     rays_o = _dev(rays_o, "rays_o").contiguous()
     rays_d = _dev(rays_d, "rays_d").contiguous()
@@ -244,8 +247,13 @@ def field_rays_save(rays_o: torch.Tensor, rays_d: torch.Tensor, z: torch.Tensor,
     raw = torch.empty(n, s, 5 + ins_num, dtype=torch.float32, device=rays_o.device)
     save = torch.empty(load().dmn_field_save_floats(n * s), dtype=torch.float32, device=rays_o.device)
     with _timed("field_fwd_save", n * s):
-        check(load().dmn_field_fwd_rays_save(ptr(rays_o), ptr(rays_d), ptr(zz), stride, n, s, ptr(blob), ins_num,
-                                             ptr(raw), ptr(save), current_stream()), "dmn_field_fwd_rays_save")
+        if precision == "fp32":
+            check(load().dmn_field_fwd_rays_save(ptr(rays_o), ptr(rays_d), ptr(zz), stride, n, s, ptr(blob), ins_num,
+                                                 ptr(raw), ptr(save), current_stream()), "dmn_field_fwd_rays_save")
+        else:
+            check(load().dmn_field_fwd_rays_x3_save(ptr(rays_o), ptr(rays_d), ptr(zz), stride, n, s, ptr(blob),
+                                                    ins_num, precision_code(precision), ptr(raw), ptr(save),
+                                                    current_stream()), "dmn_field_fwd_rays_x3_save")
     return raw, save
 
 

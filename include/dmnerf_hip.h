@@ -116,6 +116,11 @@ long dmn_field_save_floats(long n_points);
 long dmn_field_grad_floats(long n_points, int ins_num);
 int dmn_field_fwd_rays_save(const float* rays_o, const float* rays_d, const float* z, long z_ray_stride, long n_rays,
                             int n_samples, const float* blob, int ins_num, float* raw, float* save, void* stream);
+/* the same with the split-precision forward (x3 blob); DMN_PREC_BF16X3 only: there is no place to consult the fp16
+ * range flag between forward and backward */
+int dmn_field_fwd_rays_x3_save(const float* rays_o, const float* rays_d, const float* z, long z_ray_stride, long n_rays,
+                               int n_samples, const void* blob, int ins_num, int precision, float* raw, float* save,
+                               void* stream);
 long dmn_field_bwd_blob_floats(int ins_num);
 int dmn_field_bwd_pack_index(int ins_num, int32_t* index_out);
 long dmn_field_wgrad_index_len(int ins_num);

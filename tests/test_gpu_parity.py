@@ -523,7 +523,11 @@ def test_training_gradients_match_reference_golden(golden, precision):
             # resampled depths, and the reference disagrees with ITSELF there by 3.5e-2 (its fp64 run against
             # these fp32 goldens; cumprod's backward divides by 1 - alpha + 1e-10): 5e-2 end to end, and
             # test_fine_stage_gradients_on_golden_depths holds the fine stage itself to 5e-3.
-            assert err < (1e-4 if tag == "c" else 5e-2), (tag, name, err)
+            # With precision != "fp32" the training forward runs in bf16x3 (1e-5 on the activations): a handful of
+            # ReLUs of the 3072 points sit on the other side of zero, and the compositing gradient concentrates on few
+            # samples per ray, so one such unit moves a gradient by up to 2.5e-2 of its scale (observed, mlps.5.bias);
+            # test_field_backward_kernels_match_library_gemm_backward holds that mode to 1e-4 away from such units.
+            assert err < (1e-4 if (tag == "c" and precision == "fp32") else 5e-2), (tag, name, err)
     print(f"{precision}: worst gradient rel err {worst:.2e}")
     # an optimizer step through the standard torch API works on the module's parameters (train_dmsr.py:127-128)
     opt = torch.optim.Adam(list(coarse.parameters()) + list(fine.parameters()), lr=5e-4, betas=(0.9, 0.999))
@@ -612,9 +616,9 @@ def _min_abs_preactivation(net, o, d, z):
     return low.reshape(z.shape)
 
 
-@pytest.mark.parametrize("wgrad", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("fwd,wgrad", [("fp32", "fp32"), ("fp32", "bf16x3"), ("bf16x3", "bf16x3")])
 @pytest.mark.parametrize("ins_num,n,s", [(13, 37, 64), (93, 11, 100), (40, 5, 192), (13, 700, 64)])
-def test_field_backward_kernels_match_library_gemm_backward(ins_num, n, s, wgrad, monkeypatch):
+def test_field_backward_kernels_match_library_gemm_backward(ins_num, n, s, fwd, wgrad, monkeypatch):
     """HIP backward (save record -> backward-data kernel -> split-K weight-gradient kernel) against autograd
     through library GEMMs on the device, every parameter of the network, ragged point counts, 1..3 logit tiles."""
     from dm_nerf_amd import autograd
@@ -627,13 +631,14 @@ def test_field_backward_kernels_match_library_gemm_backward(ins_num, n, s, wgrad
     g_raw = rng.standard_normal((n, s, 5 + ins_num)).astype(np.float32)
     # A ReLU whose pre-activation is within rounding of zero may open in one forward and close in the other; that
     # is a different function, not an error.  Points with such a unit get no gradient in this comparison.
-    fragile = H(_min_abs_preactivation(net, G(o), G(d), G(z))) < 1e-5
-    assert fragile.mean() < 0.25
+    # (the bf16x3 forward differs from torch's by ~1e-5 of the activation scale, the exact one by ~1e-6)
+    fragile = H(_min_abs_preactivation(net, G(o), G(d), G(z))) < (1e-5 if fwd == "fp32" else 1e-4)
+    assert fragile.mean() < (0.25 if fwd == "fp32" else 0.9)
     g_raw[fragile] = 0.0
     grads = {}
     for tag, fn in (("hip", FieldFn), ("lib", FieldFnLibrary)):
         net.zero_grad()
-        raw = fn.apply(G(o), G(d), G(z), net, "fp32", *net.parameters())
+        raw = fn.apply(G(o), G(d), G(z), net, fwd, *net.parameters())
         (raw * G(g_raw)).sum().backward()
         grads[tag] = {k: H(p.grad).copy() for k, p in net.named_parameters()}
         if tag == "hip":
@@ -645,7 +650,7 @@ def test_field_backward_kernels_match_library_gemm_backward(ins_num, n, s, wgrad
         err = rel_err(grads["hip"][k], grads["lib"][k])
         worst = max(worst, err)
         assert err < 1e-4, (k, err)
-    print(f"ins_num={ins_num} M={n * s} wgrad={wgrad}: worst rel err vs library backward {worst:.2e}")
+    print(f"ins_num={ins_num} M={n * s} forward={fwd} wgrad={wgrad}: worst rel err vs library backward {worst:.2e}")
 
 
 def test_field_backward_respects_detach_and_frozen_parameters():

@@ -76,8 +76,9 @@ class FieldFn(torch.autograd.Function):
     def backward(ctx, g_raw):
         model = ctx.model
         n_params = sum(n for _, n, _ in ctx.meta)
-        flat = ops.field_backward(g_raw, ctx.save, model.blob("bwd"), model.ins_num, model.wgrad_index(), n_params,
-                                  wgrad_precision=WGRAD_PRECISION)
+        blob = model.blob("bwd" if DATA_PRECISION == "fp32" else "bwd_x3")
+        flat = ops.field_backward(g_raw, ctx.save, blob, model.ins_num, model.wgrad_index(), n_params,
+                                  wgrad_precision=WGRAD_PRECISION, data_precision=DATA_PRECISION)
         ctx.save = None
         out: List = []
         at = 0
@@ -114,6 +115,7 @@ class FieldFnLibrary(torch.autograd.Function):
 
 
 FIELD_BACKWARD = "hip"          # "library": FieldFnLibrary
+DATA_PRECISION = "bf16x3"       # backward-data chain: "bf16x3" or "fp32" (exact MFMA); masks come from the save record
 WGRAD_PRECISION = "bf16x3"      # weight-gradient GEMMs: "bf16x3" (three bf16 MFMAs per product) or "fp32" (exact MFMA)
 
 

@@ -19,102 +19,11 @@
 
 #include "../../include/dmnerf_hip.h"
 #include "field_common.h"
+#include "field_x3.h"
 
 using namespace dmn;
 
-#ifndef DMN_X3_PREFETCH
-#define DMN_X3_PREFETCH 2
-#endif
-
 namespace {
-
-struct PrecF16 {
-  typedef _Float16 elem;
-  typedef _Float16 frag __attribute__((ext_vector_type(8)));
-  static constexpr bool kCheckRange = true;
-  static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-  }
-};
-struct PrecBF16 {
-  typedef __bf16 elem;
-  typedef __bf16 frag __attribute__((ext_vector_type(8)));
-  static constexpr bool kCheckRange = false;
-  static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-  }
-};
-
-constexpr int kLdsBytes = 2 * kX3StageBytes + kConstFloats * 4;   // 146,432 B
-
-struct Ctx {
-  const char* stream;   // weight stream in global memory
-  char* lds;
-  const char* buf;      // this lane's read base inside the current stage
-  int g, G;             // next stage to begin, number of stages
-  int wave_s, lane;
-#ifdef DMN_STAMPS
-  unsigned long long t_dma = 0, t_bar = 0;
-#endif
-};
-
-// each wave DMA-copies 16 of the stage's 64 chunks
-__device__ __forceinline__ void load_stage(const Ctx& c, int g) {
-  const char* src = c.stream + (long)g * kX3StageBytes + (c.wave_s * 16) * 1024 + c.lane * 16;
-  char* dst = c.lds + (g & 1) * kX3StageBytes + (c.wave_s * 16) * 1024;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) glds16(src + q * 1024, dst + q * 1024);
-}
-
-// Barrier that retires stage g (its DMA has landed, every wave is done with stage g-1).  The DMA of stage
-// g+1 into the other buffer is NOT issued here: 4 waves x 16 pieces right behind the barrier queue up on the
-// CU's one address unit (16 cycles per 1 KiB piece) while the MFMAs wait in order behind them -- a quarter of
-// the kernel when measured.  load_piece() below spreads them one per step over the first half of the stage.
-__device__ __forceinline__ void stage_begin(Ctx& c) {
-#ifdef DMN_STAMPS   // diagnostic build only (tools/stamps.sh): cycles spent waiting at the stage barrier
-  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-  __syncthreads();
-  const unsigned long long t2 = __builtin_amdgcn_s_memtime();
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-  c.t_dma += t1 - t0;
-  c.t_bar += t2 - t1;
-#else
-  __syncthreads();
-#endif
-  c.buf = c.lds + (c.g & 1) * kX3StageBytes + c.lane * 16;
-  ++c.g;
-}
-
-// piece q (0..15) of this wave's share of the NEXT stage (index c.g after stage_begin).  Past the end of the
-// stream the source clamps to the last stage and the copy lands in the buffer nobody reads any more.
-__device__ __forceinline__ void load_piece(const Ctx& c, int q) {
-  const int g = c.g < c.G ? c.g : c.G - 1;
-  const char* src = c.stream + (long)g * kX3StageBytes + (c.wave_s * 16 + q) * 1024 + c.lane * 16;
-  char* dst = c.lds + (c.g & 1) * kX3StageBytes + (c.wave_s * 16 + q) * 1024;
-  glds16(src, dst);
-}
-
-// PIN keeps the conversion where it is written (in the MFMA shadow of the next tile): without it the compiler
-// sinks all 128 conversions of a layer to their first use in the next layer and keeps 8 accumulators alive.
-template <class P, bool PIN = false>
-__device__ __forceinline__ void split_pair(float x0, float x1, typename P::frag& hi, typename P::frag& lo, int j) {
-  typedef typename P::elem E;
-  typedef E pair __attribute__((ext_vector_type(2)));
-  pair hp, lp;
-  hp[0] = (E)x0;
-  hp[1] = (E)x1;
-  lp[0] = (E)(x0 - (float)hp[0]);
-  lp[1] = (E)(x1 - (float)hp[1]);
-  if (PIN) asm volatile("" : "+v"(hp), "+v"(lp));
-  hi[j] = hp[0];
-  hi[j + 1] = hp[1];
-  lo[j] = lp[0];
-  lo[j + 1] = lp[1];
-}
 
 // ---- tile epilogues: piece q (0..7) handles accumulator registers 2q, 2q+1 of tile t -----------
 // -> next layer's operand fragments (register 16t + r is element (r & 7) of k-step 2t + (r >> 3))
@@ -195,63 +104,6 @@ __device__ __forceinline__ void flush_mask(float* dst, unsigned* msk) {
     dst[w * 64] = __uint_as_float(msk[w]);
     msk[w] = 0u;
   }
-}
-
-// One layer: NT output tiles x (NKS + NKX) k-steps of 16; xh/xl: main operand fragments,
-// eh/el: extra fragments (position / direction encodings) appended to the k range.
-template <class P, int NT, int NKS, int NKX, class Epi>
-__device__ __forceinline__ void layer_x3(Ctx& c, const float* bias, const typename P::frag* xh,
-                                         const typename P::frag* xl, const typename P::frag* eh,
-                                         const typename P::frag* el, const Epi& epi) {
-  typedef typename P::frag frag;
-  constexpr int NK = NKS + NKX;
-  constexpr int STEPS = NT * NK;
-  constexpr int PPS = (8 + NK - 1) / NK;   // epilogue pieces per k-step
-  f32x16 acc[2];
-  constexpr int PF = DMN_X3_PREFETCH;       // A-fragment prefetch distance in steps; ring of PF + 1
-  frag ah[PF + 1], al[PF + 1];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {          // bias = initial accumulator
-      const f32x4 b = *reinterpret_cast<const f32x4*>(bias + t * 16 + v * 4);
-      acc[t & 1][4 * v + 0] = b.x; acc[t & 1][4 * v + 1] = b.y; acc[t & 1][4 * v + 2] = b.z; acc[t & 1][4 * v + 3] = b.w;
-    }
-#pragma unroll
-    for (int ks = 0; ks < NK; ++ks) {
-      const int step = t * NK + ks;
-      if ((step & 31) == 0) {              // 32 steps = 64 chunks = one stage
-        stage_begin(c);
-#pragma unroll
-        for (int d = 0; d < PF; ++d)
-          if (step + d < STEPS) {
-            ah[(step + d) % (PF + 1)] = *reinterpret_cast<const frag*>(c.buf + ((2 * (step + d)) & 63) * 1024);
-            al[(step + d) % (PF + 1)] = *reinterpret_cast<const frag*>(c.buf + ((2 * (step + d) + 1) & 63) * 1024);
-          }
-      }
-      if (step + PF < STEPS && ((step + PF) >> 5) == (step >> 5)) {   // PF steps ahead, same stage
-        ah[(step + PF) % (PF + 1)] = *reinterpret_cast<const frag*>(c.buf + ((2 * (step + PF)) & 63) * 1024);
-        al[(step + PF) % (PF + 1)] = *reinterpret_cast<const frag*>(c.buf + ((2 * (step + PF) + 1) & 63) * 1024);
-      }
-      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above this step's MFMAs
-      if (t > 0) {
-#pragma unroll
-        for (int q = ks * PPS; q < (ks + 1) * PPS && q < 8; ++q) epi(t - 1, q, acc[(t - 1) & 1]);
-      }
-      const frag bh = ks < NKS ? xh[ks < NKS ? ks : 0] : eh[ks < NKS ? 0 : ks - NKS];
-      const frag bl = ks < NKS ? xl[ks < NKS ? ks : 0] : el[ks < NKS ? 0 : ks - NKS];
-      acc[t & 1] = P::mfma(ah[step % (PF + 1)], bl, acc[t & 1]);
-      acc[t & 1] = P::mfma(al[step % (PF + 1)], bh, acc[t & 1]);
-      acc[t & 1] = P::mfma(ah[step % (PF + 1)], bh, acc[t & 1]);
-      if ((step & 31) < 16) load_piece(c, step & 31);     // one DMA piece per step, behind this step's MFMAs
-    }
-  }
-  if ((STEPS & 31) != 0 && (STEPS & 31) < 16) {          // a short last stage still owes the rest of its pieces
-#pragma unroll
-    for (int q = (STEPS & 31); q < 16; ++q) load_piece(c, q);
-  }
-#pragma unroll
-  for (int q = 0; q < 8; ++q) epi(NT - 1, q, acc[(NT - 1) & 1]);
 }
 
 template <class P, int T, bool SAVE>
@@ -412,10 +264,11 @@ int launch_prec(const FieldArgs& a, int ins_num, int precision, hipStream_t st) 
 
 // blob gather with the hi / lo split; entry i < kConstFloats is an fp32 constant, the rest are halves
 template <class E>
-__global__ void pack_x3_kernel(const float* __restrict__ params, const int32_t* __restrict__ index, char* __restrict__ blob) {
+__global__ void pack_x3_kernel(const float* __restrict__ params, const int32_t* __restrict__ index, long index_len,
+                               char* __restrict__ blob) {
   float* cst = reinterpret_cast<float*>(blob);
   E* stream = reinterpret_cast<E*>(blob + kConstFloats * 4);
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < kX3IndexLen; i += (long)gridDim.x * blockDim.x) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < index_len; i += (long)gridDim.x * blockDim.x) {
     const int32_t k = index[i];
     const float v = k < 0 ? 0.f : params[k];
     if (i < kConstFloats) {
@@ -431,16 +284,23 @@ __global__ void pack_x3_kernel(const float* __restrict__ params, const int32_t* 
 
 }  // namespace
 
-extern "C" int dmn_field_pack_x3(const float* params, const int32_t* index, int precision, void* blob, void* stream) {
-  if (!params || !index || !blob) return DMN_ERR_BAD_ARG;
+extern "C" int dmn_field_pack_x3_n(const float* params, const int32_t* index, long index_len, int precision,
+                                   void* blob, void* stream) {
+  if (!params || !index || !blob || index_len < kConstFloats) return DMN_ERR_BAD_ARG;
   const dim3 grid(2048), block(256);
   if (precision == DMN_PREC_FP16X3)
-    hipLaunchKernelGGL(pack_x3_kernel<_Float16>, grid, block, 0, (hipStream_t)stream, params, index, (char*)blob);
+    hipLaunchKernelGGL(pack_x3_kernel<_Float16>, grid, block, 0, (hipStream_t)stream, params, index, index_len,
+                       (char*)blob);
   else if (precision == DMN_PREC_BF16X3)
-    hipLaunchKernelGGL(pack_x3_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, params, index, (char*)blob);
+    hipLaunchKernelGGL(pack_x3_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, params, index, index_len,
+                       (char*)blob);
   else
     return DMN_ERR_BAD_ARG;
   return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
+}
+
+extern "C" int dmn_field_pack_x3(const float* params, const int32_t* index, int precision, void* blob, void* stream) {
+  return dmn_field_pack_x3_n(params, index, kX3IndexLen, precision, blob, stream);
 }
 
 extern "C" int dmn_field_fwd_rays_x3(const float* rays_o, const float* rays_d, const float* z, long z_ray_stride,

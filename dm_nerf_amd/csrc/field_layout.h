@@ -210,6 +210,18 @@ DMN_HD constexpr long bwd_blob_floats(int ins_num) {
   return (long)kConstFloats + (long)bwd_total_stages(ins_tiles(ins_num)) * kStageFloats;
 }
 
+// Backward-data stream in the split-precision format (64-chunk stages, tiles outer, [hi, lo] chunk pairs):
+constexpr int kBwdX3StageInsO = 0;     // ins_linear^T:            4 tiles x 2T k-steps -> 1 stage
+constexpr int kBwdX3StageInsH = 1;     // ins_feature_linears.0^T: 8 x 8  -> 128 chunks, 2 stages
+constexpr int kBwdX3StageRgbH = 3;     // rgb_feature_linears.0^T (feature columns): 8 x 8 -> 2 stages
+constexpr int kBwdX3StageRgbF = 5;     // rgb_feature_linear^T:    8 x 16 -> 4 stages
+DMN_HD constexpr int bwd_x3_stage_mlp(int l) { return kBwdX3StageRgbF + 4 + 4 * (7 - l); }   // l = 7..1
+constexpr int kBwdX3Stages = kBwdX3StageRgbF + 4 + 7 * 4;   // 37
+constexpr long kBwdX3StreamHalfs = (long)kBwdX3Stages * kX3StageChunks * kX3ChunkHalfs;
+constexpr long kBwdX3BlobBytes = (long)kConstFloats * 4 + kBwdX3StreamHalfs * 2;
+constexpr long kBwdX3IndexLen = (long)kConstFloats + kBwdX3StreamHalfs;
+constexpr int kConstZeros = 3592;      // const floats 3592..3839 are zero padding: initial accumulators of the backward
+
 // Weight-gradient GEMMs: dW[o][k] = sum over points of G[o][point] * X[k][point], G rows from the gradient
 // record, X rows from the save record (or, for the heads, G from the head tile).  Shapes in 32-row tiles.
 struct WGemm {

@@ -97,8 +97,10 @@ struct Builder {
 // ---- split-precision stream (v_mfma_f32_32x32x16_{f16,bf16}) ---------------------------------
 // One layer: tiles in the outer loop, k-steps inner, [hi, lo] chunk pair per (tile, k-step).
 // col(i, h): input column held by element i = 8*ks + j of lane-half h, or -1.
+// transposed: the layer multiplies by W^T (backward data): row indexes W's columns, the k feature its rows.
 template <class Col>
-void layer_x3(int32_t* stream, int stage0, int n_tiles, int n_ksteps, int w_off, int fan_in, int n_rows, Col col) {
+void layer_x3(int32_t* stream, int stage0, int n_tiles, int n_ksteps, int w_off, int fan_in, int n_rows, Col col,
+              bool transposed = false) {
   for (int t = 0; t < n_tiles; ++t)
     for (int ks = 0; ks < n_ksteps; ++ks)
       for (int part = 0; part < 2; ++part) {
@@ -108,7 +110,7 @@ void layer_x3(int32_t* stream, int stage0, int n_tiles, int n_ksteps, int w_off,
           for (int j = 0; j < 8; ++j) {
             int row = 32 * t + (lane & 31);
             int k = col(8 * ks + j, lane >> 5);
-            c[lane * 8 + j] = (k < 0 || row >= n_rows) ? -1 : w_off + row * fan_in + k;
+            c[lane * 8 + j] = (k < 0 || row >= n_rows) ? -1 : (transposed ? w_off + k * fan_in + row : w_off + row * fan_in + k);
           }
       }
 }
@@ -239,6 +241,33 @@ extern "C" int dmn_field_bwd_pack_index(int ins_num, int32_t* index_out) {
     for (int l = 7; l >= 1; --l)
       b.kstep8T(bwd_stage_mlp(T, l), j, P.mlp_w[l], mlp_fan_in(l), [&](int h) { return feat_of(j, h); });
   }
+  return DMN_OK;
+}
+
+extern "C" long dmn_field_bwd_blob_x3_bytes(int ins_num) {
+  if (!supported(ins_num)) return DMN_ERR_BAD_ARG;
+  return kBwdX3BlobBytes;
+}
+
+extern "C" long dmn_field_bwd_pack_index_x3_len(int ins_num) {
+  if (!supported(ins_num)) return DMN_ERR_BAD_ARG;
+  return kBwdX3IndexLen;
+}
+
+extern "C" int dmn_field_bwd_pack_index_x3(int ins_num, int32_t* index_out) {
+  if (!index_out || !supported(ins_num)) return DMN_ERR_BAD_ARG;
+  const int T = ins_tiles(ins_num);
+  const ParamOffsets P = param_offsets(ins_num);
+  std::fill(index_out, index_out + kBwdX3IndexLen, -1);
+  fill_const(index_out, P, ins_num);
+  int32_t* s = index_out + kConstFloats;
+  auto act = [](int i, int h) { return feat_of(i, h); };
+  layer_x3(s, kBwdX3StageInsO, 4, 2 * T, P.inso_w, kHalf, kHalf,
+           [&](int i, int h) { int ch = feat_of(i, h); return ch <= ins_num ? ch : -1; }, true);
+  layer_x3(s, kBwdX3StageInsH, 8, 8, P.insh_w, kWidth, kWidth, act, true);
+  layer_x3(s, kBwdX3StageRgbH, 8, 8, P.rgbh_w, kWidth + kDirCh, kWidth, act, true);
+  layer_x3(s, kBwdX3StageRgbF, 8, 16, P.rgbf_w, kWidth, kWidth, act, true);
+  for (int l = 7; l >= 1; --l) layer_x3(s, bwd_x3_stage_mlp(l), 8, 16, P.mlp_w[l], mlp_fan_in(l), kWidth, act, true);
   return DMN_OK;
 }
 

@@ -84,10 +84,10 @@ class DM_NeRF(nn.Module):
         return [p for _, p in self.named_parameters()]      # registration order = state_dict order
 
     def blob(self, precision: str = "fp32") -> torch.Tensor:
-        """Device blob consumed by the field kernel of the given precision ("bwd": the transposed-weight blob of
-        the backward-data kernel); re-gathered only when a parameter changed (optimizer steps and
-        load_state_dict bump the tensors' version counters)."""
-        if precision != "bwd":
+        """Device blob consumed by the field kernel of the given precision ("bwd" / "bwd_x3": the transposed-weight
+        blobs of the exact and the bf16x3 backward-data kernel); re-gathered only when a parameter changed
+        (optimizer steps and load_state_dict bump the tensors' version counters)."""
+        if precision not in ("bwd", "bwd_x3"):
             ops.precision_code(precision)
         params = self._ordered_params()
         dev = params[0].device
@@ -95,14 +95,20 @@ class DM_NeRF(nn.Module):
         cached = self._blobs.get(precision)
         if cached is not None and cached[0] == key:
             return cached[1]
-        flavour = precision if precision in ("fp32", "bwd") else "x3"
+        flavour = precision if precision in ("fp32", "bwd", "bwd_x3") else "x3"
         index = self._indices.get((flavour, dev))
         if index is None:
-            make = {"fp32": ops.pack_index, "bwd": ops.bwd_pack_index, "x3": ops.pack_index_x3}[flavour]
+            make = {"fp32": ops.pack_index, "bwd": ops.bwd_pack_index, "bwd_x3": ops.bwd_pack_index_x3,
+                    "x3": ops.pack_index_x3}[flavour]
             index = self._indices[(flavour, dev)] = make(self.ins_num, dev)
         with torch.no_grad():
             flat = torch.cat([p.detach().reshape(-1).float() for p in params])
-        blob = ops.pack_blob_x3(flat, index, self.ins_num, precision) if flavour == "x3" else ops.pack_blob(flat, index)
+        if flavour == "x3":
+            blob = ops.pack_blob_x3(flat, index, self.ins_num, precision)
+        elif flavour == "bwd_x3":
+            blob = ops.pack_bwd_blob_x3(flat, index, self.ins_num)
+        else:
+            blob = ops.pack_blob(flat, index)
         self._blobs[precision] = (key, blob)
         return blob
 

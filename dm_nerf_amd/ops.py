@@ -223,6 +223,25 @@ def bwd_pack_index(ins_num: int, device) -> torch.Tensor:
     return torch.from_numpy(idx).to(device)
 
 
+def bwd_pack_index_x3(ins_num: int, device) -> torch.Tensor:
+    lib = load()
+    n = lib.dmn_field_bwd_pack_index_x3_len(ins_num)
+    if n < 0:
+        raise ValueError(f"ins_num={ins_num} unsupported (ins_num + 1 must be <= {MAX_INS_CHANNELS})")
+    idx = np.empty(n, dtype=np.int32)
+    check(lib.dmn_field_bwd_pack_index_x3(ins_num, idx.ctypes.data), "dmn_field_bwd_pack_index_x3")
+    return torch.from_numpy(idx).to(device)
+
+
+def pack_bwd_blob_x3(flat_params: torch.Tensor, index: torch.Tensor, ins_num: int) -> torch.Tensor:
+    _dev(flat_params, "flat_params")
+    lib = load()
+    blob = torch.empty(lib.dmn_field_bwd_blob_x3_bytes(ins_num), dtype=torch.uint8, device=flat_params.device)
+    check(lib.dmn_field_pack_x3_n(ptr(flat_params), ptr(index), index.numel(), PRECISIONS["bf16x3"], ptr(blob),
+                                  current_stream()), "dmn_field_pack_x3_n")
+    return blob
+
+
 def wgrad_index(ins_num: int, device) -> torch.Tensor:
     lib = load()
     n = lib.dmn_field_wgrad_index_len(ins_num)
@@ -259,11 +278,13 @@ def field_rays_save(rays_o: torch.Tensor, rays_d: torch.Tensor, z: torch.Tensor,
 
 def field_backward(g_raw: torch.Tensor, save: torch.Tensor, bwd_blob: torch.Tensor, ins_num: int,
                    wgrad_idx: torch.Tensor, n_params: int, splits: Optional[int] = None,
-                   wgrad_precision: str = "bf16x3") -> torch.Tensor:
-    """dL/d raw [N,S,C] + save record -> flat parameter gradient (state_dict order).  ``wgrad_precision``:
-    arithmetic of the weight-gradient GEMMs, "fp32" (exact MFMA) or "bf16x3" (three bf16 MFMAs per product)."""
-    if wgrad_precision not in ("fp32", "bf16x3"):
-        raise ValueError("wgrad_precision must be 'fp32' or 'bf16x3' (gradients underflow fp16)")
+                   wgrad_precision: str = "bf16x3", data_precision: str = "fp32") -> torch.Tensor:
+    """dL/d raw [N,S,C] + save record -> flat parameter gradient (state_dict order).  ``data_precision`` /
+    ``wgrad_precision``: arithmetic of the backward-data chain and of the weight-gradient GEMMs, "fp32" (exact
+    MFMA) or "bf16x3" (three bf16 MFMAs per product); ``bwd_blob`` must be the blob of ``data_precision``."""
+    for prec in (wgrad_precision, data_precision):
+        if prec not in ("fp32", "bf16x3"):
+            raise ValueError("backward precisions are 'fp32' or 'bf16x3' (gradients underflow fp16)")
     _dev(g_raw, "g_raw")
     g_raw = g_raw.contiguous()
     m = g_raw.shape[0] * g_raw.shape[1]
@@ -278,8 +299,12 @@ def field_backward(g_raw: torch.Tensor, save: torch.Tensor, bwd_blob: torch.Tens
         splits = max(1, min(85, n_tiles // 8))          # 9 big GEMMs x 85 slices = 3 workgroups per CU
     grec = torch.empty(lib.dmn_field_grad_floats(m, ins_num), dtype=torch.float32, device=dev)
     with _timed("field_bwd_data", m):
-        check(lib.dmn_field_bwd_data(ptr(g_raw), ptr(save), ptr(bwd_blob), m, ins_num, ptr(grec), current_stream()),
-              "dmn_field_bwd_data")
+        if data_precision == "fp32":
+            check(lib.dmn_field_bwd_data(ptr(g_raw), ptr(save), ptr(bwd_blob), m, ins_num, ptr(grec),
+                                         current_stream()), "dmn_field_bwd_data")
+        else:
+            check(lib.dmn_field_bwd_data_x3(ptr(g_raw), ptr(save), ptr(bwd_blob), m, ins_num, ptr(grec),
+                                            current_stream()), "dmn_field_bwd_data_x3")
     work = torch.empty(lib.dmn_field_wgrad_workspace_floats(ins_num, splits), dtype=torch.float32, device=dev)
     grads = torch.zeros(n_params, dtype=torch.float32, device=dev)
     with _timed("field_bwd_weights", m):

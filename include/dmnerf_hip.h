@@ -94,6 +94,9 @@ long dmn_field_blob_x3_bytes(int ins_num);
 long dmn_field_pack_index_x3_len(int ins_num);
 int dmn_field_pack_index_x3(int ins_num, int32_t* index_out);
 int dmn_field_pack_x3(const float* params, const int32_t* index, int precision, void* blob, void* stream);
+/* the same gather for any x3-format table of `index_len` entries (forward or backward-data blob) */
+int dmn_field_pack_x3_n(const float* params, const int32_t* index, long index_len, int precision, void* blob,
+                        void* stream);
 int dmn_field_fwd_rays_x3(const float* rays_o, const float* rays_d, const float* z, long z_ray_stride, long n_rays,
                           int n_samples, const void* blob, int ins_num, int precision, float* raw, int* status,
                           void* stream);
@@ -123,6 +126,13 @@ int dmn_field_fwd_rays_x3_save(const float* rays_o, const float* rays_d, const f
                                void* stream);
 long dmn_field_bwd_blob_floats(int ins_num);
 int dmn_field_bwd_pack_index(int ins_num, int32_t* index_out);
+/* split-precision flavour of the backward-data step (bf16, three MFMA products per fp32 product): x3-format
+ * transposed-weight blob (pack with dmn_field_pack_x3_n and DMN_PREC_BF16X3) and the kernel */
+long dmn_field_bwd_blob_x3_bytes(int ins_num);
+long dmn_field_bwd_pack_index_x3_len(int ins_num);
+int dmn_field_bwd_pack_index_x3(int ins_num, int32_t* index_out);
+int dmn_field_bwd_data_x3(const float* g_raw, const float* save, const void* bwd_blob_x3, long n_points, int ins_num,
+                          float* grad_record, void* stream);
 long dmn_field_wgrad_index_len(int ins_num);
 int dmn_field_wgrad_index(int ins_num, int32_t* index_out);
 int dmn_field_bwd_data(const float* g_raw, const float* save, const float* bwd_blob, long n_points, int ins_num,

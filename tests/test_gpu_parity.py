@@ -616,14 +616,16 @@ def _min_abs_preactivation(net, o, d, z):
     return low.reshape(z.shape)
 
 
-@pytest.mark.parametrize("fwd,wgrad", [("fp32", "fp32"), ("fp32", "bf16x3"), ("bf16x3", "bf16x3")])
+@pytest.mark.parametrize("fwd,data,wgrad", [("fp32", "fp32", "fp32"), ("fp32", "fp32", "bf16x3"),
+                                            ("fp32", "bf16x3", "bf16x3"), ("bf16x3", "bf16x3", "bf16x3")])
 @pytest.mark.parametrize("ins_num,n,s", [(13, 37, 64), (93, 11, 100), (40, 5, 192), (13, 700, 64)])
-def test_field_backward_kernels_match_library_gemm_backward(ins_num, n, s, fwd, wgrad, monkeypatch):
+def test_field_backward_kernels_match_library_gemm_backward(ins_num, n, s, fwd, data, wgrad, monkeypatch):
     """HIP backward (save record -> backward-data kernel -> split-K weight-gradient kernel) against autograd
     through library GEMMs on the device, every parameter of the network, ragged point counts, 1..3 logit tiles."""
     from dm_nerf_amd import autograd
     from dm_nerf_amd.autograd import FieldFn, FieldFnLibrary
     monkeypatch.setattr(autograd, "WGRAD_PRECISION", wgrad)
+    monkeypatch.setattr(autograd, "DATA_PRECISION", data)
     _, _, net, _, _ = nets(ins_num, 3, 4)
     rng = np.random.default_rng(900 + ins_num + n)
     o, d, _, _ = cases.path_rays(n, seed=31 + n)
@@ -650,7 +652,7 @@ def test_field_backward_kernels_match_library_gemm_backward(ins_num, n, s, fwd, 
         err = rel_err(grads["hip"][k], grads["lib"][k])
         worst = max(worst, err)
         assert err < 1e-4, (k, err)
-    print(f"ins_num={ins_num} M={n * s} forward={fwd} wgrad={wgrad}: worst rel err vs library backward {worst:.2e}")
+    print(f"ins_num={ins_num} M={n * s} forward={fwd} data={data} wgrad={wgrad}: worst rel err vs library backward {worst:.2e}")
 
 
 def test_field_backward_respects_detach_and_frozen_parameters():

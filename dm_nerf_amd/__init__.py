@@ -15,7 +15,7 @@ from .helpers import get_rays_k, get_select_crop, get_select_full, sample_pdf, z
 from .manipulator import manipulator_nerf, manipulator_render
 from .render import dm_nerf, render_train
 from .tester import render_image, render_test
-from . import parallel, trainer
+from . import autograd, parallel, trainer
 
 # nerf-pytorch names used by BASELINE.json's north_star
 render = dm_nerf

@@ -142,6 +142,19 @@ int dmn_field_bwd_weights(const float* save, const float* grad_record, long n_po
                           const int32_t* wgrad_index, int splits, int precision, float* workspace,
                           float* grads_flat, int accumulate, void* stream);
 
+/* ---- emptiness penalizer (networks/penalizer.py:5-62: ins_penalizer -> emptiness_penalizer) ------------------
+ * raw [N,S,C] (logits = channels 4..C-1), z (stride), depth [N] (the rendered depth, detached by the caller as
+ * penalizer.py:59 does), rays_d [N,3].  Forward fills sums4 (device doubles): sum of the "before" term, number of
+ * samples before the tolerance band, sum of the "middle" term, number of samples inside the band;
+ * loss = sums4[0] / ((C-4) * max(sums4[1], 1e-8)) + sums4[2] / max(sums4[3], 1e-8).  Backward writes
+ * g_raw [N,S,C] = g_loss[0] * d loss / d raw (channels 0..3 zero).                                          */
+int dmn_penalizer_fwd(const float* raw, const float* z, long z_ray_stride, const float* depth, const float* rays_d,
+                      long n_rays, int n_samples, int channels, float tolerance, float deta_w, double* sums4,
+                      void* stream);
+int dmn_penalizer_bwd(const float* raw, const float* z, long z_ray_stride, const float* depth, const float* rays_d,
+                      long n_rays, int n_samples, int channels, float tolerance, float deta_w, const double* sums4,
+                      const float* g_loss, float* g_raw, void* stream);
+
 /* ---- render_train (networks/render.py:6-28) / manipulator_render (manipulator.py:86-105) --
  * raw [N,S,C], z (stride), rays_d [N,3] -> rgb [N,3], weights [N,S], depth [N],
  * ins [N, C-5] (keep_last = 0, render_train drops the last channel, render.py:26) or

@@ -289,6 +289,39 @@ def render_image(H: int, W: int, K, c2w: torch.Tensor, coarse: Params, fine: Par
 # --------------------------------------------------------------------------------------
 # synthetic cameras (conventions of datasets/loader_dmsr.py:29-34,171-172)
 # --------------------------------------------------------------------------------------
+# --------------------------------------------------------------------------------------
+# training loss head on the path's raw output (row N2)
+# --------------------------------------------------------------------------------------
+def emptiness_penalizer(raw: torch.Tensor, z: torch.Tensor, depth: torch.Tensor, rays_d: torch.Tensor,
+                        tolerance: float, deta_w: float) -> torch.Tensor:
+    """Emptiness loss on the per-sample instance logits (networks/penalizer.py:5-55; ``ins_penalizer`` :58-62
+    passes ``depth[..., None].detach()``).  ``raw [N,S,4+ins_num+1]``, ``z [N,S]``, ``depth [N]`` -> scalar.
+
+    Samples more than ``tolerance`` in front of the rendered depth should be "air" (last channel on, all others
+    off, weighted by 1 - Gaussian of the distance to the depth); samples within the tolerance band should not be
+    air (weighted by the Gaussian); samples behind are free."""
+    depth = depth.detach()[..., None]
+    norm = torch.norm(rays_d[..., None, :], dim=-1)                                   # :13
+    dist_before, dist_after = (depth - tolerance) * norm, (depth + tolerance) * norm  # :14-17
+    p = z * norm                                                                      # :19
+    delta = depth * norm - p                                                          # :18,22
+    width = torch.tensor([deta_w])
+    gauss = torch.exp(-(delta ** 2) / (2 * (width ** 2))) / (torch.tensor([0.4]) * torch.sqrt(torch.tensor([2 * np.pi]))) + 1e-8
+    before = (p < dist_before).float()                                                # :27
+    after = (p > dist_after).float()
+    middle = 1 - (after + before)                                                     # :29
+    pred = torch.sigmoid(raw[..., 4:])                                                # :32-33
+    target = torch.zeros_like(pred)
+    target[..., -1] = 1                                                               # :37-38
+    bce = -target * torch.log(pred + 1e-8) - (1 - target) * torch.log(1 - pred + 1e-8)
+    loss_before = torch.sum(bce * ((1 - gauss) * before)[..., None]) / (
+        pred.shape[-1] * torch.maximum(torch.sum(before), torch.tensor([1e-8])))      # :40-43
+    air = pred[..., -1]
+    loss_middle = torch.sum(-torch.log(1 - air + 1e-8) * (gauss * middle)) / torch.maximum(
+        torch.sum(middle), torch.tensor([1e-8]))                                      # :46-52
+    return (loss_before + loss_middle).reshape(())
+
+
 def dmsr_intrinsics(H: int, W: int, camera_angle_x: float = 0.6911) -> np.ndarray:
     f = 0.5 * W / math.tan(0.5 * camera_angle_x)
     return np.array([[f, 0.0, W / 2.0], [0.0, -f, H / 2.0], [0.0, 0.0, -1.0]], dtype=np.float64)

@@ -75,6 +75,27 @@ def composite_case(n_rays: int, n_samples: int, channels: int, seed: int):
     return raw, z, d
 
 
+# ---- G10: emptiness-penalizer inputs (raw, z, depth, rays_d) ---------------------------
+# tag -> (rays, samples, channels, tolerance, deta_w, seed); 0.05 / 0.05 are the reference configs' values
+PENALIZER_CASES = {"a": (24, 64, 18, 0.05, 0.05, 301), "b": (12, 192, 18, 0.05, 0.05, 302),
+                   "c": (6, 64, 98, 0.3, 0.2, 303), "d": (7, 100, 11, 1.5, 0.5, 304)}
+
+
+def penalizer_case(n_rays: int, n_samples: int, channels: int, seed: int):
+    rng = np.random.default_rng(seed)
+    raw = rng.standard_normal((n_rays, n_samples, channels)).astype(np.float32) * 3.0
+    raw[0, :, 4:] = 40.0                                  # saturated logits: log(1 - p + 1e-8) clamps
+    raw[1, :, 4:] = -40.0
+    z = np.sort(rng.uniform(NEAR, FAR, size=(n_rays, n_samples)).astype(np.float32), axis=-1)
+    depth = rng.uniform(NEAR + 1.0, FAR - 1.0, size=n_rays).astype(np.float32)
+    depth[2] = NEAR - 0.5                                 # surface in front of every sample: nothing "before"
+    depth[3] = FAR + 0.5                                  # behind every sample: everything "before"
+    depth[4] = z[4, n_samples // 2]                       # exactly on a sample
+    d = rng.standard_normal((n_rays, 3)).astype(np.float32)
+    d[5] *= 1e-2
+    return raw, z, depth, d
+
+
 # ---- G5: sampler inputs ------------------------------------------------------------
 def sampler_case(n_rays: int = 48, seed: int = 15):
     rng = np.random.default_rng(seed)

@@ -239,9 +239,24 @@ def g9_selectors():
          crop_n_ins=n_ins)
 
 
+def g10_penalizer():
+    """ins_penalizer (networks/penalizer.py:58-62) and the gradient autograd gives it w.r.t. raw."""
+    from networks import penalizer as ref_penalizer
+    out = {}
+    for tag, (n, s, c, tol, width, seed) in cases.PENALIZER_CASES.items():
+        raw, z, depth, d = cases.penalizer_case(n, s, c, seed)
+        raw_t = torch.from_numpy(raw).requires_grad_(True)
+        loss = ref_penalizer.ins_penalizer(raw_t, torch.from_numpy(z), torch.from_numpy(depth), torch.from_numpy(d),
+                                           SimpleNamespace(tolerance=tol, deta_w=width))
+        loss.backward()
+        out.update({f"{tag}_digest": cases.digest(raw, z, depth, d), f"{tag}_loss": loss.detach().reshape(()),
+                    f"{tag}_grad": raw_t.grad})
+    save("g10_penalizer.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     table = {"g1": g1_rays, "g2": g2_encode, "g3": g3_field, "g4": g4_composite, "g5": g5_sampler,
-             "g6": g6_path, "g7": g7_gradients, "g8": g8_image, "g9": g9_selectors}
+             "g6": g6_path, "g7": g7_gradients, "g8": g8_image, "g9": g9_selectors, "g10": g10_penalizer}
     for key in which:
         table[key]()

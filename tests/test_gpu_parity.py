@@ -673,6 +673,29 @@ def test_field_backward_respects_detach_and_frozen_parameters():
             assert float(p.grad.abs().max()) > 0.0, k
 
 
+# ---- emptiness penalizer (row N2) ---------------------------------------------------------------------------
+def test_emptiness_penalizer_matches_reference_golden(golden):
+    """Loss and d loss / d raw against the reference's ins_penalizer + autograd (G10): Gaussian band around the
+    rendered depth, saturated logits, depth in front of / behind all samples, C = 98."""
+    g = golden("g10_penalizer.npz")
+    for tag, (n, s, c, tol, width, seed) in cases.PENALIZER_CASES.items():
+        raw, z, depth, d = cases.penalizer_case(n, s, c, seed)
+        assert cases.digest(raw, z, depth, d) == str(g[f"{tag}_digest"])
+        raw_g = G(raw).requires_grad_(True)
+        loss = dm.ins_penalizer(raw_g, G(z), G(depth), G(d), SimpleNamespace(tolerance=tol, deta_w=width))
+        assert loss.shape == () and abs(float(loss) - float(g[f"{tag}_loss"])) < 2e-6 * abs(float(g[f"{tag}_loss"]))
+        (2.5 * loss).backward()
+        assert rel_err(H(raw_g.grad), 2.5 * g[f"{tag}_grad"]) < 1e-5, tag
+        assert float(raw_g.grad[..., :4].abs().max()) == 0.0
+    # the same through the trainer's hook on a stride-0 depth lattice
+    zl = dm.z_val_sample(6, cases.NEAR, cases.FAR, 64)
+    raw, _, depth, d = cases.penalizer_case(6, 64, 18, 305)
+    a = dm.emptiness_penalizer(G(raw), zl, G(depth)[:, None], G(d), 0.05, 0.05)
+    b = oracle.emptiness_penalizer(torch.from_numpy(raw), zl.cpu().contiguous(), torch.from_numpy(depth),
+                                   torch.from_numpy(d), 0.05, 0.05)
+    assert abs(float(a) - float(b)) < 2e-6 * abs(float(b))
+
+
 # ---- training ray selectors (row N1) --------------------------------------------------------------------
 def test_ray_selectors_match_reference_golden(golden):
     g = golden("g9_selectors.npz")

@@ -168,3 +168,16 @@ def test_manipulator_variant_keeps_air_channel():
     assert ins.shape[-1] == 14 and ins2.shape[-1] == 13
     np.testing.assert_array_equal(ins[..., :-1].numpy(), ins2.numpy())
     np.testing.assert_array_equal(w.numpy(), w2.numpy())
+
+
+def test_emptiness_penalizer_restatement_matches_reference_golden(golden):
+    """oracle.emptiness_penalizer against the reference's ins_penalizer and its autograd gradient (G10)."""
+    g = golden("g10_penalizer.npz")
+    for tag, (n, s, c, tol, width, seed) in cases.PENALIZER_CASES.items():
+        raw, z, depth, d = cases.penalizer_case(n, s, c, seed)
+        assert cases.digest(raw, z, depth, d) == str(g[f"{tag}_digest"])
+        raw_t = torch.from_numpy(raw).requires_grad_(True)
+        loss = oracle.emptiness_penalizer(raw_t, torch.from_numpy(z), torch.from_numpy(depth), torch.from_numpy(d), tol, width)
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), float(g[f"{tag}_loss"]), rtol=1e-6)
+        np.testing.assert_allclose(raw_t.grad.numpy(), g[f"{tag}_grad"], rtol=1e-5, atol=1e-9)

@@ -13,6 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rays", type=int, default=4096)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--precision", default="fp32")
+ap.add_argument("--penalize", action="store_true", help="add the emptiness penalizer (configs: tolerance = deta_w = 0.05)")
 ns = ap.parse_args()
 dev = torch.device("cuda", 0)
 args = dm.default_args(ins_num=13, perturb=1.0, is_train=True, precision=ns.precision, device=dev)
@@ -25,11 +26,13 @@ rays = torch.stack([ro.reshape(-1, 3)[pick], rd.reshape(-1, 3)[pick]], 0)
 target = torch.rand(ns.rays, 3, device=dev)
 z = dm.z_val_sample(ns.rays, args.near, args.far, args.N_samples)
 opt = trainer.make_optimizer(coarse, fine)
-trainer.train_step(0, rays, target, (pos, view, coarse, fine, args), z, opt)
+args.tolerance, args.deta_w = 0.05, 0.05
+pen = (lambda raw, zz, depth: dm.ins_penalizer(raw, zz, depth, rays[1], args)) if ns.penalize else None
+trainer.train_step(0, rays, target, (pos, view, coarse, fine, args), z, opt, penalizer=pen)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for i in range(ns.steps):
-    trainer.train_step(i + 1, rays, target, (pos, view, coarse, fine, args), z, opt)
+    trainer.train_step(i + 1, rays, target, (pos, view, coarse, fine, args), z, opt, penalizer=pen)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / ns.steps
 print(json.dumps({"metric": "training rays/s (HIP field fwd+save, HIP composite bwd, HIP field backward-data + weight-gradient kernels, Adam)",
                   "rays_per_step": ns.rays, "ms_per_step": dt * 1e3, "value": ns.rays / dt, "unit": "rays/s",
-                  "precision_forward": ns.precision, "peak_mem_gb": torch.cuda.max_memory_allocated() / 2**30}))
+                  "precision_forward": ns.precision, "emptiness_penalizer": bool(ns.penalize), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2**30}))

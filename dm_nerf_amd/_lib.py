@@ -61,6 +61,8 @@ SIGNATURES = {
     "dmn_field_bwd_weights": (c_int, [_P, _P, c_long, c_int, _P, c_int, c_int, _P, _P, c_int, _P]),
     "dmn_penalizer_fwd": (c_int, [_P, _P, c_long, _P, _P, c_long, c_int, c_int, c_float, c_float, _P, _P]),
     "dmn_penalizer_bwd": (c_int, [_P, _P, c_long, _P, _P, c_long, c_int, c_int, c_float, c_float, _P, _P, _P, _P]),
+    "dmn_ins_stats_fwd": (c_int, [_P, _P, _P, c_long, c_int, c_int, _P, _P]),
+    "dmn_ins_stats_bwd": (c_int, [_P, _P, c_long, c_int, c_int, _P, _P, _P]),
     "dmn_composite_fwd": (c_int, [_P, _P, c_long, _P, c_long, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "dmn_composite_bwd": (c_int, [_P, _P, c_long, _P, _P, _P, _P, _P, _P, c_long, c_int, c_int, c_int, _P, _P]),
     "dmn_sample_pdf": (c_int, [_P, c_long, _P, c_long, _P, c_long, c_long, c_int, c_int, _P, _P]),

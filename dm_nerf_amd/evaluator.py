@@ -1,0 +1,78 @@
+"""Loss heads of the training step with the reference's names (networks/evaluator.py:11-74).
+
+``ins_criterion`` matches predicted instance columns to ground-truth classes with the Hungarian algorithm on the
+host (scipy, exactly as the reference does) -- but the cost matrices come from class-wise column statistics reduced
+by a HIP kernel (``csrc/ins_stats.hip``) instead of three ``[ins, ins, N]`` broadcast tensors, and the gradient
+flows back through the matching gather kernel."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import check, current_stream, load, ptr
+
+img2mse = lambda x, y: torch.mean((x - y) ** 2)                                     # evaluator.py:11
+mse2psnr = lambda x: -10.0 * torch.log(x) / np.log(10.0)                            # evaluator.py:15
+
+
+class _ClassStatsFn(torch.autograd.Function):
+    """pred [N,K], rays grouped by class -> stats [3, V, K] (sums of log(p+1e-8), log(1-p+1e-8), p per class)."""
+
+    @staticmethod
+    def forward(ctx, pred, classes, n_classes):
+        pred = ops._dev(pred, "pred_ins").contiguous()
+        n, k = pred.shape
+        order = torch.argsort(classes, stable=True)
+        seg = torch.zeros(n_classes + 1, dtype=torch.int64, device=pred.device)
+        seg[1:] = torch.cumsum(torch.bincount(classes, minlength=n_classes), 0)
+        stats = torch.empty(3, n_classes, k, dtype=torch.float32, device=pred.device)
+        check(load().dmn_ins_stats_fwd(ptr(pred), ptr(order), ptr(seg), n, k, n_classes, ptr(stats), current_stream()),
+              "dmn_ins_stats_fwd")
+        ctx.save_for_backward(pred, classes)
+        ctx.n_classes = n_classes
+        return stats
+
+    @staticmethod
+    def backward(ctx, g_stats):
+        pred, classes = ctx.saved_tensors
+        n, k = pred.shape
+        g_pred = torch.empty_like(pred)
+        check(load().dmn_ins_stats_bwd(ptr(pred), ptr(classes), n, k, ctx.n_classes, ptr(g_stats.contiguous()),
+                                       ptr(g_pred), current_stream()), "dmn_ins_stats_bwd")
+        return g_pred, None, None
+
+
+def ins_criterion(pred_ins: torch.Tensor, gt_labels: torch.Tensor, ins_num: int):
+    """``(ins_loss_sum, valid_ce, invalid_ce, valid_siou)`` of networks/evaluator.py:19-38 for ``pred_ins [N, ins_num]``
+    (the rendered, sigmoided instance map) and integer ``gt_labels [N]``.  All four are 0-dim tensors
+    (the reference's ``invalid_ce`` is ``tensor([0])`` when every column is matched)."""
+    from scipy.optimize import linear_sum_assignment
+
+    if pred_ins.dim() != 2 or pred_ins.shape[1] != ins_num or gt_labels.shape[0] != pred_ins.shape[0]:
+        raise ValueError("pred_ins must be [N, ins_num] and gt_labels [N]")
+    n = pred_ins.shape[0]
+    valid, classes = torch.unique(gt_labels.long(), return_inverse=True)              # :21, :25 (sorted labels)
+    v = int(valid.numel())                                                            # :24
+    if v > ins_num:
+        raise ValueError(f"{v} distinct labels but only {ins_num} instance columns")
+    stats = _ClassStatsFn.apply(pred_ins, classes.contiguous(), v)
+    s1, s0, tp = stats[0], stats[1], stats[2]
+    count = torch.bincount(classes, minlength=v).to(torch.float32)[:, None]
+    cost_ce = -(s1 + (s0.sum(0, keepdim=True) - s0)) / n                              # :60
+    fp = tp.sum(0, keepdim=True) - tp                                                 # :63-65
+    fn = count - tp
+    cost_siou = 1.0 - tp / (tp + fp + fn + 1e-6)                                      # :66-67
+    with torch.no_grad():                                                             # reorder(), :42-52
+        rows, cols = linear_sum_assignment((cost_ce + cost_siou).cpu().numpy())
+        unmatched = np.array(sorted(set(range(ins_num)) - set(cols.tolist())), dtype=np.int64)
+    rows_t = torch.as_tensor(rows, device=pred_ins.device)
+    cols_t = torch.as_tensor(cols, device=pred_ins.device)
+    valid_ce = cost_ce[rows_t, cols_t].mean()                                         # :27
+    valid_siou = cost_siou[rows_t, cols_t].mean()                                     # :33
+    if unmatched.size:                                                                # :29-32
+        col_sums = tp.sum(0)
+        invalid_ce = col_sums[torch.as_tensor(unmatched, device=pred_ins.device)].sum() / (n * unmatched.size)
+    else:
+        invalid_ce = torch.zeros((), device=pred_ins.device)
+    return valid_ce + invalid_ce + valid_siou, valid_ce, invalid_ce, valid_siou

@@ -3,13 +3,13 @@
 
     optimizer = make_optimizer(model_coarse, model_fine, lrate=5e-4)            # train_dmsr.py:127-128
     losses = train_step(i, batch_rays, target_rgb, nerf, z_vals, optimizer, lrate=5e-4, lrate_decay=500,
-                        ins_loss=lambda pred: ins_criterion(pred, target_i, ins_num)[0],    # reference's own head
+                        ins_loss=lambda pred: dm_nerf_amd.ins_criterion(pred, target_i, ins_num)[0],
                         penalizer=lambda raw, z, depth: dm_nerf_amd.ins_penalizer(raw, z, depth, rays_d, args))
 
-The emptiness penalizer (``networks/penalizer.py``) is ``dm_nerf_amd.ins_penalizer`` (fused HIP kernels, same
-signature); the instance-matching loss (``networks/evaluator.py:19-74``, scipy Hungarian on the host) is the
-reference's PyTorch function and plugs in unchanged as a callable; without them the step optimises the two colour
-terms only."""
+The emptiness penalizer (``networks/penalizer.py``) is ``dm_nerf_amd.ins_penalizer`` and the instance-matching loss
+(``networks/evaluator.py:19-74``) is ``dm_nerf_amd.ins_criterion`` (HIP kernels for the reductions and gradients,
+scipy Hungarian on the host as in the reference), both with the reference's signatures; the reference's own
+functions plug in just as well.  Without them the step optimises the two colour terms only."""
 from __future__ import annotations
 
 from typing import Callable, Dict, Optional

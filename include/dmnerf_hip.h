@@ -155,6 +155,17 @@ int dmn_penalizer_bwd(const float* raw, const float* z, long z_ray_stride, const
                       long n_rays, int n_samples, int channels, float tolerance, float deta_w, const double* sums4,
                       const float* g_loss, float* g_raw, void* stream);
 
+/* ---- statistics of the instance-matching loss (networks/evaluator.py:19-74) ----------------------------------
+ * pred [N, n_cols] (rendered instance map, n_cols = ins_num <= 128), rays grouped by ground-truth class:
+ * order [N] (ray indices, class by class), segments [n_classes + 1] (offsets into order), both int64 on the device.
+ * stats [3][n_classes][n_cols]: per class and column the sums of log(pred + 1e-8), log(1 - pred + 1e-8), pred,
+ * from which the reference's cost_ce / TP / FP / FN follow without its [ins, ins, N] broadcasts.  Backward:
+ * classes [N] (class of each ray) and g_stats -> g_pred [N, n_cols].                                         */
+int dmn_ins_stats_fwd(const float* pred, const long* order, const long* segments, long n_rays, int n_cols,
+                      int n_classes, float* stats, void* stream);
+int dmn_ins_stats_bwd(const float* pred, const long* classes, long n_rays, int n_cols, int n_classes,
+                      const float* g_stats, float* g_pred, void* stream);
+
 /* ---- render_train (networks/render.py:6-28) / manipulator_render (manipulator.py:86-105) --
  * raw [N,S,C], z (stride), rays_d [N,3] -> rgb [N,3], weights [N,S], depth [N],
  * ins [N, C-5] (keep_last = 0, render_train drops the last channel, render.py:26) or

@@ -322,6 +322,30 @@ def emptiness_penalizer(raw: torch.Tensor, z: torch.Tensor, depth: torch.Tensor,
     return (loss_before + loss_middle).reshape(())
 
 
+def ins_criterion(pred_ins: torch.Tensor, gt_labels: torch.Tensor, ins_num: int):
+    """Instance-matching loss (networks/evaluator.py:19-74): one-hot ground truth over the labels present,
+    cross-entropy and soft-IoU cost matrices by broadcasting, Hungarian matching (scipy) on the rows of the classes
+    present, ``(sum, valid_ce, invalid_ce, valid_siou)``."""
+    from scipy.optimize import linear_sum_assignment
+    valid = torch.unique(gt_labels)                                                    # :21
+    v = len(valid)
+    gt = torch.zeros(gt_labels.shape[0], ins_num)
+    gt[..., :v] = torch.nn.functional.one_hot(gt_labels.long())[..., valid.long()].float()   # :22-25
+    p, g = pred_ins.permute(1, 0)[None, :, :], gt.permute(1, 0)[:, None, :]           # :55-58
+    cost_ce = torch.mean(-g * torch.log(p + 1e-8) - (1 - g) * torch.log(1 - p + 1e-8), dim=-1)
+    tp = torch.sum(p * g, dim=-1)
+    fp = torch.sum(p, dim=-1) - tp
+    fn = torch.sum(g, dim=-1) - tp
+    cost_siou = 1.0 - tp / (tp + fp + fn + 1e-6)                                       # :63-67
+    with torch.no_grad():                                                              # :42-52
+        rows, cols = linear_sum_assignment((cost_ce + cost_siou)[:v].numpy())
+        rest = np.array(sorted(set(range(ins_num)) - set(cols.tolist())), dtype=np.int64)
+    valid_ce = torch.mean(cost_ce[rows, cols])                                         # :27
+    invalid_ce = torch.mean(pred_ins[:, rest]) if rest.size else torch.zeros(())       # :29-32
+    valid_siou = torch.mean(cost_siou[rows, cols])                                     # :33
+    return valid_ce + invalid_ce + valid_siou, valid_ce, invalid_ce, valid_siou
+
+
 def dmsr_intrinsics(H: int, W: int, camera_angle_x: float = 0.6911) -> np.ndarray:
     f = 0.5 * W / math.tan(0.5 * camera_angle_x)
     return np.array([[f, 0.0, W / 2.0], [0.0, -f, H / 2.0], [0.0, 0.0, -1.0]], dtype=np.float64)

@@ -96,6 +96,26 @@ def penalizer_case(n_rays: int, n_samples: int, channels: int, seed: int):
     return raw, z, depth, d
 
 
+# ---- G11: instance-matching loss inputs (rendered instance map, integer labels) --------
+# tag -> (rays, ins_num, labels present, seed)
+CRITERION_CASES = {"a": (96, 13, (0, 2, 3, 7, 12), 311), "b": (64, 13, tuple(range(13)), 312),
+                   "c": (80, 93, (1, 5, 40, 41, 90, 92), 313), "d": (40, 7, (4,), 314)}
+
+
+def criterion_case(n_rays: int, ins_num: int, present, seed: int):
+    rng = np.random.default_rng(seed)
+    labels = rng.choice(np.asarray(present), size=n_rays).astype(np.int64)
+    labels[: len(present)] = present                      # every listed label occurs
+    pred = rng.uniform(0.02, 0.98, size=(n_rays, ins_num)).astype(np.float32)
+    perm = rng.permutation(ins_num)                       # a (shuffled) column responds to each class
+    for k, lab in enumerate(present):
+        hit = labels == lab
+        pred[hit, perm[k]] = rng.uniform(0.6, 0.999, size=int(hit.sum())).astype(np.float32)
+    pred[0, :] = 1.0                                      # saturated predictions: the 1e-8 clamps
+    pred[1, :] = 0.0
+    return pred, labels
+
+
 # ---- G5: sampler inputs ------------------------------------------------------------
 def sampler_case(n_rays: int = 48, seed: int = 15):
     rng = np.random.default_rng(seed)

@@ -254,9 +254,25 @@ def g10_penalizer():
     save("g10_penalizer.npz", **out)
 
 
+def g11_criterion():
+    """ins_criterion (networks/evaluator.py:19-38) with its Hungarian matching, and the gradient w.r.t. the map."""
+    from networks import evaluator as ref_evaluator
+    out = {}
+    for tag, (n, ins_num, present, seed) in cases.CRITERION_CASES.items():
+        pred, labels = cases.criterion_case(n, ins_num, present, seed)
+        pred_t = torch.from_numpy(pred).requires_grad_(True)
+        total, ce, inv, siou = ref_evaluator.ins_criterion(pred_t, torch.from_numpy(labels), ins_num)
+        total.sum().backward()
+        out.update({f"{tag}_digest": cases.digest(pred, labels), f"{tag}_total": total.detach().reshape(()),
+                    f"{tag}_ce": ce.detach().reshape(()), f"{tag}_inv": inv.detach().float().reshape(()),
+                    f"{tag}_siou": siou.detach().reshape(()), f"{tag}_grad": pred_t.grad})
+    save("g11_criterion.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     table = {"g1": g1_rays, "g2": g2_encode, "g3": g3_field, "g4": g4_composite, "g5": g5_sampler,
-             "g6": g6_path, "g7": g7_gradients, "g8": g8_image, "g9": g9_selectors, "g10": g10_penalizer}
+             "g6": g6_path, "g7": g7_gradients, "g8": g8_image, "g9": g9_selectors, "g10": g10_penalizer,
+             "g11": g11_criterion}
     for key in which:
         table[key]()

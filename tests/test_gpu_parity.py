@@ -696,6 +696,25 @@ def test_emptiness_penalizer_matches_reference_golden(golden):
     assert abs(float(a) - float(b)) < 2e-6 * abs(float(b))
 
 
+# ---- instance-matching loss on class statistics (row N4) ---------------------------------------------------
+def test_ins_criterion_matches_reference_golden(golden):
+    """The four loss terms and d total / d pred against the reference's ins_criterion (G11): 5 of 13 labels present,
+    all present, ins_num = 93, a single class; saturated predictions."""
+    g = golden("g11_criterion.npz")
+    for tag, (n, ins_num, present, seed) in cases.CRITERION_CASES.items():
+        pred, labels = cases.criterion_case(n, ins_num, present, seed)
+        assert cases.digest(pred, labels) == str(g[f"{tag}_digest"])
+        pred_g = G(pred).requires_grad_(True)
+        total, ce, inv, siou = dm.ins_criterion(pred_g, torch.from_numpy(labels).to(DEV), ins_num)
+        for name, got in (("total", total), ("ce", ce), ("inv", inv), ("siou", siou)):
+            want = float(g[f"{tag}_{name}"])
+            assert abs(float(got.detach()) - want) <= 2e-6 * max(abs(want), 1e-3), (tag, name, float(got.detach()), want)
+        total.backward()
+        got, want = H(pred_g.grad), g[f"{tag}_grad"]
+        np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-7 * np.abs(want).max())
+        np.testing.assert_allclose(got[2:], want[2:], rtol=2e-5, atol=2e-6 * np.abs(want[2:]).max())   # unsaturated rows
+
+
 # ---- training ray selectors (row N1) --------------------------------------------------------------------
 def test_ray_selectors_match_reference_golden(golden):
     g = golden("g9_selectors.npz")

@@ -181,3 +181,17 @@ def test_emptiness_penalizer_restatement_matches_reference_golden(golden):
         loss.backward()
         np.testing.assert_allclose(loss.item(), float(g[f"{tag}_loss"]), rtol=1e-6)
         np.testing.assert_allclose(raw_t.grad.numpy(), g[f"{tag}_grad"], rtol=1e-5, atol=1e-9)
+
+
+def test_ins_criterion_restatement_matches_reference_golden(golden):
+    """oracle.ins_criterion against the reference's (G11), values and gradient."""
+    g = golden("g11_criterion.npz")
+    for tag, (n, ins_num, present, seed) in cases.CRITERION_CASES.items():
+        pred, labels = cases.criterion_case(n, ins_num, present, seed)
+        assert cases.digest(pred, labels) == str(g[f"{tag}_digest"])
+        pred_t = torch.from_numpy(pred).requires_grad_(True)
+        total, ce, inv, siou = oracle.ins_criterion(pred_t, torch.from_numpy(labels), ins_num)
+        total.backward()
+        for name, got in (("total", total), ("ce", ce), ("inv", inv), ("siou", siou)):
+            np.testing.assert_allclose(float(got.detach()), float(g[f"{tag}_{name}"]), rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(pred_t.grad.numpy(), g[f"{tag}_grad"], rtol=1e-5, atol=1e-3)

@@ -94,6 +94,44 @@ def cpu_baseline(K, pose, params, sample_rays: int, chunk: int):
     return sample_rays / dt, rgb, ins
 
 
+def training_leg(nerf, K, pose, device, n_rays: int = 4096, steps: int = 4):
+    """BASELINE config 4 on one GPU, outside the timed region: `steps` optimisation steps of `n_rays` random rays of
+    the same camera (stochastic path, colour + instance-matching + emptiness losses, Adam), hand-written forward and
+    backward kernels, once with the exact forward and once with the bf16x3 forward."""
+    from dm_nerf_amd import trainer
+    pos, view, coarse, fine, args = nerf
+    state = [{k: v.clone() for k, v in m.state_dict().items()} for m in (coarse, fine)]
+    targs = dm.default_args(**{**vars(args), "perturb": 1.0, "is_train": True, "tolerance": 0.05, "deta_w": 0.05})
+    g = torch.Generator(device=device).manual_seed(2)
+    pick = torch.randperm(H * W, device=device, generator=g)[:n_rays]
+    ro, rd = dm.get_rays_k(H, W, K, pose)
+    rays = torch.stack([ro.reshape(-1, 3)[pick], rd.reshape(-1, 3)[pick]], 0)
+    target = torch.rand(n_rays, 3, device=device, generator=g)
+    labels = torch.randint(0, INS_NUM, (n_rays,), device=device, generator=g)
+    z = dm.z_val_sample(n_rays, targs.near, targs.far, targs.N_samples)
+    result = {"rays_per_step": n_rays, "losses": "mse + ins_criterion + ins_penalizer (coarse and fine), Adam 5e-4",
+              "backward": "HIP: backward-data + weight-gradient kernels (bf16x3), compositing backward"}
+    coarse.train(); fine.train()
+    for prec in ("fp32", "bf16x3"):
+        targs.precision = prec
+        opt = trainer.make_optimizer(coarse, fine)
+        run = lambda i: trainer.train_step(
+            i, rays, target, (pos, view, coarse, fine, targs), z, opt,
+            ins_loss=lambda pred: dm.ins_criterion(pred, labels, INS_NUM)[0],
+            penalizer=lambda raw, zz, depth: dm.ins_penalizer(raw, zz, depth, rays[1], targs))
+        run(0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            last = run(i + 1)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        result[f"forward_{prec}"] = {"ms_per_step": dt * 1e3, "rays_per_s": n_rays / dt, "loss_total": last["total"]}
+    coarse.load_state_dict(state[0]); fine.load_state_dict(state[1])
+    coarse.eval(); fine.eval()
+    return result
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,6 +146,8 @@ def main():
                     choices=["fp32", "fp16x3", "bf16x3"],
                     help="field-kernel arithmetic: fp32 = exact fp32 MFMA; fp16x3 / bf16x3 = three 16-bit MFMAs "
                          "per product (hi/lo split, fp32 accumulate)")
+    ap.add_argument("--no-train-leg", action="store_true",
+                    help="skip the extra training-step measurement after the timed region (N = 1 only)")
     ap.add_argument("--no-fp32-leg", action="store_true",
                     help="skip the extra 2 images rendered in exact-fp32 mode after the timed region (N = 1 only)")
     ns = ap.parse_args()
@@ -245,6 +285,9 @@ def main():
                                                "frac": tf32 / PEAK_F32_MFMA_TFLOPS},
                                   "max_abs_rgb_diff_vs_headline_mode": float((rgb32 - rgb).abs().max())}
         args.precision = ns.precision
+
+    if world == 1 and not ns.no_train_leg:
+        out["training_step"] = training_leg(nerf, K, poses[0], device)
 
     if ns.cpu_rays > 0:
         cpu_rps, cpu_rgb, cpu_ins = cpu_baseline(K, pose, params, ns.cpu_rays, CPU_CHUNK)

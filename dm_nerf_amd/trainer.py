@@ -56,8 +56,8 @@ def train_step(i: int, batch_rays, target_rgb, nerf, z_vals_coarse, optimizer, l
     optimizer.step()
     for group in optimizer.param_groups:                                            # applied after the step, :68-72
         group["lr"] = decayed_lrate(i, lrate, lrate_decay)
-    return {k: float(v) for k, v in terms.items()} | {"total": float(total),
-                                                      "psnr_fine": float(-10.0 * torch.log10(mse_f))}
+    return {k: float(v.detach()) for k, v in terms.items()} | {"total": float(total.detach()),
+                                                               "psnr_fine": float(-10.0 * torch.log10(mse_f.detach()))}
 
 
 def checkpoint_dict(i: int, model_coarse, model_fine, optimizer) -> dict:

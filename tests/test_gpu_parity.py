@@ -618,7 +618,7 @@ def _min_abs_preactivation(net, o, d, z):
 
 @pytest.mark.parametrize("fwd,data,wgrad", [("fp32", "fp32", "fp32"), ("fp32", "fp32", "bf16x3"),
                                             ("fp32", "bf16x3", "bf16x3"), ("bf16x3", "bf16x3", "bf16x3")])
-@pytest.mark.parametrize("ins_num,n,s", [(13, 37, 64), (93, 11, 100), (40, 5, 192), (13, 700, 64)])
+@pytest.mark.parametrize("ins_num,n,s", [(13, 37, 64), (93, 11, 100), (40, 5, 192), (13, 700, 64), (127, 3, 64)])
 def test_field_backward_kernels_match_library_gemm_backward(ins_num, n, s, fwd, data, wgrad, monkeypatch):
     """HIP backward (save record -> backward-data kernel -> split-K weight-gradient kernel) against autograd
     through library GEMMs on the device, every parameter of the network, ragged point counts, 1..3 logit tiles."""
@@ -653,6 +653,32 @@ def test_field_backward_kernels_match_library_gemm_backward(ins_num, n, s, fwd, 
         worst = max(worst, err)
         assert err < 1e-4, (k, err)
     print(f"ins_num={ins_num} M={n * s} forward={fwd} data={data} wgrad={wgrad}: worst rel err vs library backward {worst:.2e}")
+
+
+def test_field_backward_is_linear_and_additive_over_rays_at_training_size():
+    """BASELINE config 4 size (4096 rays x 192 samples through the fine network): the parameter gradient is linear in
+    dL/d raw and additive over a partition of the rays -- size-independent properties of the split-K reduction."""
+    from dm_nerf_amd.autograd import FieldFn
+    _, _, net, _, _ = nets(13, 3, 4)
+    n, s = 4096, 192
+    rng = np.random.default_rng(77)
+    o, d, _, _ = cases.path_rays(n, seed=77)
+    z = G(np.sort(rng.uniform(cases.NEAR, cases.FAR, (n, s)).astype(np.float32), -1))
+    g_raw = G(rng.standard_normal((n, s, 18)).astype(np.float32))
+
+    def grads(rows, scale=1.0):
+        net.zero_grad()
+        raw = FieldFn.apply(G(o)[rows], G(d)[rows], z[rows], net, "fp32", *net.parameters())
+        (raw * (scale * g_raw[rows])).sum().backward()
+        return torch.cat([p.grad.reshape(-1) for p in net.parameters()]).double()
+
+    whole = grads(slice(0, n))
+    assert torch.isfinite(whole).all() and float(whole.abs().max()) > 0
+    scale = float(whole.abs().max())
+    assert float((grads(slice(0, n), -2.0) + 2.0 * whole).abs().max()) < 2e-5 * scale          # linear (bf16x3 rounding)
+    parts = grads(slice(0, 1000)) + grads(slice(1000, 3333)) + grads(slice(3333, n))
+    assert float((parts - whole).abs().max()) < 2e-5 * scale                                   # additive
+    assert torch.equal(grads(slice(0, n)), whole)                                              # deterministic
 
 
 def test_field_backward_respects_detach_and_frozen_parameters():

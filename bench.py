@@ -289,7 +289,7 @@ def main():
     if world == 1 and not ns.no_train_leg:
         out["training_step"] = training_leg(nerf, K, poses[0], device)
 
-    if ns.cpu_rays > 0:
+    if ns.cpu_rays > 0 and world == 1:       # the CPU baseline is timed on rank 0 at N = 1 only
         cpu_rps, cpu_rgb, cpu_ins = cpu_baseline(K, pose, params, ns.cpu_rays, CPU_CHUNK)
         got = rgb.reshape(-1, 3)[: ns.cpu_rays].cpu()
         mse = float(torch.mean((got - cpu_rgb) ** 2))

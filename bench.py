@@ -142,7 +142,7 @@ def main():
                          "tiling parameter (results are partition-invariant bit for bit, tests/test_gpu_parity.py), "
                          "and 16384 saves 1.7 %% of launch ramp on the same device (4096: --chunk 4096)")
     ap.add_argument("--cpu-rays", type=int, default=8192, help="rays of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--precision", default=os.environ.get("DMNERF_PRECISION", "fp16x3"),
+    ap.add_argument("--precision", default=os.environ.get("DMNERF_PRECISION", "bf16x3"),
                     choices=["fp32", "fp16x3", "bf16x3"],
                     help="field-kernel arithmetic: fp32 = exact fp32 MFMA; fp16x3 / bf16x3 = three 16-bit MFMAs "
                          "per product (hi/lo split, fp32 accumulate)")

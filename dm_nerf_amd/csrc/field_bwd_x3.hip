@@ -35,9 +35,8 @@ struct EpiGrad {
   const unsigned* msk;     // sign bits of the layer's ReLU (MASK)
   float sig;               // dL/d sigma, folded into the trunk-output gradient (0 elsewhere)
   const float* dw;         // density weights of this lane-half
-  __device__ __forceinline__ void operator()(int t, int q, const f32x16& acc) const {
+  __device__ __forceinline__ void operator()(int t, int q, float x0, float x1) const {
     const int i = 16 * t + 2 * q;
-    float x0 = acc[2 * q], x1 = acc[2 * q + 1];
     if (SIG) {
       x0 = fmaf(sig, dw[i], x0);
       x1 = fmaf(sig, dw[i + 1], x1);

@@ -37,11 +37,10 @@ struct EpiSplit {
   bool dens;
   float* img = nullptr;  // training: register image of this layer's output (field_layout.h), lane offset included
   unsigned* msk = nullptr;   // training: sign bits of the ReLU layer, 32 registers per word
-  __device__ __forceinline__ void operator()(int t, int q, const f32x16& acc) const {
-    float x0 = acc[2 * q], x1 = acc[2 * q + 1];
-    if (RELU) {                              // v_med3_f32: one instruction, no canonicalising pre-max
-      x0 = __builtin_amdgcn_fmed3f(x0, 0.f, __builtin_inff());
-      x1 = __builtin_amdgcn_fmed3f(x1, 0.f, __builtin_inff());
+  __device__ __forceinline__ void operator()(int t, int q, float x0, float x1) const {
+    if (RELU) {
+      x0 = relu_bits(x0);
+      x1 = relu_bits(x1);
     }
     if (img != nullptr) {
       img[(16 * t + 2 * q) * 64] = x0;
@@ -68,8 +67,8 @@ struct EpiRgb {
   const float* rw;       // cst + kConstRgbW + h*64
   float* img = nullptr;  // training: image of the post-ReLU layer output, and its sign bits
   unsigned* msk = nullptr;
-  __device__ __forceinline__ void operator()(int t, int q, const f32x16& acc) const {
-    const float x0 = fmaxf(acc[2 * q], 0.f), x1 = fmaxf(acc[2 * q + 1], 0.f);
+  __device__ __forceinline__ void operator()(int t, int q, float a0, float a1) const {
+    const float x0 = relu_bits(a0), x1 = relu_bits(a1);
     if (img != nullptr) {
       img[(16 * t + 2 * q) * 64] = x0;
       img[(16 * t + 2 * q + 1) * 64] = x1;
@@ -86,12 +85,12 @@ struct EpiRgb {
 struct EpiStore {
   float* out;            // raw row of this lane's point, or null
   int ins_ch, h;
-  __device__ __forceinline__ void operator()(int t, int q, const f32x16& acc) const {
+  __device__ __forceinline__ void operator()(int t, int q, float x0, float x1) const {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int r = 2 * q + e;
       const int ch = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (out != nullptr && ch < ins_ch) out[4 + ch] = acc[r];
+      if (out != nullptr && ch < ins_ch) out[4 + ch] = e ? x1 : x0;
     }
   }
 };

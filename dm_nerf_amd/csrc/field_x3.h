@@ -5,6 +5,15 @@
 #pragma once
 #include "field_common.h"
 
+// Timing-only ablation switches (never defined in the product build; results are wrong with them):
+//   DMN_ABL_NODMA  the weight stream stops after the first two stages (LDS keeps realistic data)
+//   DMN_ABL_NOLDS  A fragments are read from LDS only in the first stage of a kernel, then reused
+#ifndef DMN_ABL_NODMA
+#define DMN_ABL_NODMA 0
+#endif
+#ifndef DMN_ABL_NOLDS
+#define DMN_ABL_NOLDS 0
+#endif
 #ifndef DMN_X3_PREFETCH
 #define DMN_X3_PREFETCH 2
 #endif
@@ -18,6 +27,9 @@ struct PrecF16 {
   static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   }
+  typedef _Float16 pair __attribute__((ext_vector_type(2)));
+  typedef float float2v __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ float2v widen(pair p) { return __builtin_convertvector(p, float2v); }
 };
 struct PrecBF16 {
   typedef __bf16 elem;
@@ -25,6 +37,12 @@ struct PrecBF16 {
   static constexpr bool kCheckRange = false;
   static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+  typedef __bf16 pair __attribute__((ext_vector_type(2)));
+  typedef float float2v __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ float2v widen(pair p) {   // bf16 -> f32 is a shift / a mask of the packed register
+    const unsigned u = __builtin_bit_cast(unsigned, p);
+    return (float2v){__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
   }
 };
 
@@ -75,6 +93,7 @@ __device__ __forceinline__ void stage_begin(Ctx& c) {
 // piece q (0..15) of this wave's share of the NEXT stage (index c.g after stage_begin).  Past the end of the
 // stream the source clamps to the last stage and the copy lands in the buffer nobody reads any more.
 __device__ __forceinline__ void load_piece(const Ctx& c, int q) {
+  if (DMN_ABL_NODMA && c.g >= 2) return;
   const int g = c.g < c.G ? c.g : c.G - 1;
   const char* src = c.stream + (long)g * kX3StageBytes + (c.wave_s * 16 + q) * 1024 + c.lane * 16;
   char* dst = c.lds + (c.g & 1) * kX3StageBytes + (c.wave_s * 16 + q) * 1024;
@@ -87,16 +106,37 @@ template <class P, bool PIN = false>
 __device__ __forceinline__ void split_pair(float x0, float x1, typename P::frag& hi, typename P::frag& lo, int j) {
   typedef typename P::elem E;
   typedef E pair __attribute__((ext_vector_type(2)));
-  pair hp, lp;
-  hp[0] = (E)x0;
-  hp[1] = (E)x1;
-  lp[0] = (E)(x0 - (float)hp[0]);
-  lp[1] = (E)(x1 - (float)hp[1]);
-  if (PIN) asm volatile("" : "+v"(hp), "+v"(lp));
+  typedef float float2v __attribute__((ext_vector_type(2)));
+  // one packed conversion per pair (v_cvt_pk_{f16,bf16}_f32), and the rounded values back from the packed register:
+  // written with scalar casts the compiler converts every value twice
+  const pair hp0 = __builtin_convertvector((float2v){x0, x1}, pair);
+  pair hp = hp0;
+  if (PIN) asm volatile("" : "+v"(hp));
+  const float2v back = P::widen(hp);
+  pair lp = __builtin_convertvector((float2v){x0 - back[0], x1 - back[1]}, pair);
+  if (PIN) asm volatile("" : "+v"(lp));
   hi[j] = hp[0];
   hi[j + 1] = hp[1];
   lo[j] = lp[0];
   lo[j + 1] = lp[1];
+}
+
+// ReLU as a signed-integer max on the bit pattern: one v_max_i32, where fmaxf / v_med3 cost a canonicalising
+// v_max_f32 x, x first.  Negative values (and -0, negative NaNs) give +0, everything else is unchanged.
+__device__ __forceinline__ float relu_bits(float x) {
+  const int b = __builtin_bit_cast(int, x);
+  return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+
+// Element r of a FINISHED accumulator tile, read out of its AGPR where it is used (only behind at least one full
+// k-step of MFMAs on the other tile, see layer_x3): left to itself the compiler copies the
+// whole finished tile out behind the tile's last MFMA (s_nop for the result latency + 16 v_accvgpr_read with the
+// matrix pipe idle) and reuses the same AGPRs for the next tile; the "a" constraint keeps the finished tile where
+// it is, the next tile accumulates in the other tuple, and the copies ride in the MFMA shadow two per step.
+__device__ __forceinline__ float acc_read(const f32x16& acc, int r) {
+  float x;
+  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(acc[r]));
+  return x;
 }
 
 // One layer: NT output tiles x (NKS + NKX) k-steps of 16; xh/xl: main operand fragments,
@@ -108,7 +148,11 @@ __device__ __forceinline__ void layer_x3(Ctx& c, const float* bias, const typena
   typedef typename P::frag frag;
   constexpr int NK = NKS + NKX;
   constexpr int STEPS = NT * NK;
-  constexpr int PPS = (8 + NK - 1) / NK;   // epilogue pieces per k-step
+  static_assert(NK >= 2, "the epilogue of a tile is spread over k-steps 1.. of the next one");
+  // epilogue pieces per k-step, over k-steps 1 .. NK-1 of the next tile: k-step 0 (three MFMAs on the OTHER
+  // accumulator, >= 96 cycles) covers the result latency of the finished tile's last MFMA.  acc_read() is inline
+  // asm, for which the compiler inserts no MFMA -> VALU hazard nops; reading earlier returns a stale accumulator.
+  constexpr int PPS = (8 + NK - 2) / (NK - 1);
   f32x16 acc[2];
   constexpr int PF = DMN_X3_PREFETCH;       // A-fragment prefetch distance in steps; ring of PF + 1
   frag ah[PF + 1], al[PF + 1];
@@ -131,14 +175,15 @@ __device__ __forceinline__ void layer_x3(Ctx& c, const float* bias, const typena
             al[(step + d) % (PF + 1)] = *reinterpret_cast<const frag*>(c.buf + ((2 * (step + d) + 1) & 63) * 1024);
           }
       }
-      if (step + PF < STEPS && ((step + PF) >> 5) == (step >> 5)) {   // PF steps ahead, same stage
+      if (step + PF < STEPS && ((step + PF) >> 5) == (step >> 5) && !(DMN_ABL_NOLDS && c.g > 1)) {   // PF steps ahead, same stage
         ah[(step + PF) % (PF + 1)] = *reinterpret_cast<const frag*>(c.buf + ((2 * (step + PF)) & 63) * 1024);
         al[(step + PF) % (PF + 1)] = *reinterpret_cast<const frag*>(c.buf + ((2 * (step + PF) + 1) & 63) * 1024);
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above this step's MFMAs
-      if (t > 0) {
+      if (t > 0 && ks > 0) {
 #pragma unroll
-        for (int q = ks * PPS; q < (ks + 1) * PPS && q < 8; ++q) epi(t - 1, q, acc[(t - 1) & 1]);
+        for (int q = (ks - 1) * PPS; q < ks * PPS && q < 8; ++q)
+          epi(t - 1, q, acc_read(acc[(t - 1) & 1], 2 * q), acc_read(acc[(t - 1) & 1], 2 * q + 1));
       }
       const frag bh = ks < NKS ? xh[ks < NKS ? ks : 0] : eh[ks < NKS ? 0 : ks - NKS];
       const frag bl = ks < NKS ? xl[ks < NKS ? ks : 0] : el[ks < NKS ? 0 : ks - NKS];
@@ -152,8 +197,10 @@ __device__ __forceinline__ void layer_x3(Ctx& c, const float* bias, const typena
 #pragma unroll
     for (int q = (STEPS & 31); q < 16; ++q) load_piece(c, q);
   }
+  // the last tile has no successor to hide behind: plain register reads, so that the compiler sees the MFMA -> VALU
+  // dependency and inserts the wait states itself
 #pragma unroll
-  for (int q = 0; q < 8; ++q) epi(NT - 1, q, acc[(NT - 1) & 1]);
+  for (int q = 0; q < 8; ++q) epi(NT - 1, q, acc[(NT - 1) & 1][2 * q], acc[(NT - 1) & 1][2 * q + 1]);
 }
 
 

@@ -82,3 +82,26 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("# oracle", ""), f"{f} mentions the oracle"
+
+
+def test_inline_asm_accumulator_reads_keep_their_distance_from_the_producing_mfma(tmp_path):
+    """field_x3.h reads finished accumulator tiles with inline asm (v_accvgpr_read_b32) so that they stay in their
+    AGPRs; the compiler inserts no MFMA -> VALU hazard wait states for inline asm, so the distance is guaranteed by
+    construction (one full k-step on the other tile) and checked here on the generated ISA."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from dm_nerf_amd.build import FLAGS
+    flags = [f for f in FLAGS if f not in ("-shared", "-fPIC")]
+    for src in ("field_bwd_x3.hip", "field_fwd_x3.hip"):
+        out = str(tmp_path / (src + ".s"))
+        subprocess.run([hipcc, *flags, "-S", "--cuda-device-only", "-o", out,
+                        os.path.join(root, "dm_nerf_amd", "csrc", src)], check=True, capture_output=True)
+        res = subprocess.run([sys.executable, os.path.join(root, "tools", "check_acc_hazard.py"), out],
+                             capture_output=True, text=True)
+        assert res.returncode == 0, res.stdout + res.stderr
+        assert "accumulator reads" in res.stdout

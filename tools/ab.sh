@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 PREC=$1; shift
 for rep in 1 2 3; do
   for lib in "$@"; do
-    DMNERF_LIB=$PWD/$lib python bench.py --steps 2 --warmup 1 --cpu-rays 0 --no-fp32-leg --precision $PREC 2>/dev/null \
+    DMNERF_LIB=$PWD/$lib python bench.py --steps 2 --warmup 1 --cpu-rays 0 --no-fp32-leg --no-train-leg --precision $PREC 2>/dev/null \
       | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('rep$rep', '$lib'.split('/')[-1], round(d['value']), 'rays/s  field ms', round(d['roofline']['avg_launch_ms'],4))"
   done
 done

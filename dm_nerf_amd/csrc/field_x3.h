@@ -109,11 +109,10 @@ __device__ __forceinline__ void split_pair(float x0, float x1, typename P::frag&
   typedef float float2v __attribute__((ext_vector_type(2)));
   // one packed conversion per pair (v_cvt_pk_{f16,bf16}_f32), and the rounded values back from the packed register:
   // written with scalar casts the compiler converts every value twice
-  const pair hp0 = __builtin_convertvector((float2v){x0, x1}, pair);
-  pair hp = hp0;
+  const float2v x = {x0, x1};
+  pair hp = __builtin_convertvector(x, pair);
   if (PIN) asm volatile("" : "+v"(hp));
-  const float2v back = P::widen(hp);
-  pair lp = __builtin_convertvector((float2v){x0 - back[0], x1 - back[1]}, pair);
+  pair lp = __builtin_convertvector(x - P::widen(hp), pair);          // v_pk_add_f32 with negated second operand
   if (PIN) asm volatile("" : "+v"(lp));
   hi[j] = hp[0];
   hi[j + 1] = hp[1];

@@ -43,6 +43,9 @@ SIGNATURES = {
     "dmn_field_pack_x3": (c_int, [_P, _P, c_int, _P, _P]),
     "dmn_field_fwd_rays_x3": (c_int, [_P, _P, _P, c_long, c_long, c_int, _P, c_int, c_int, _P, _P, _P]),
     "dmn_field_fwd_embedded_x3": (c_int, [_P, c_long, _P, c_int, c_int, _P, _P, _P]),
+    "dmn_render_workspace_floats": (c_long, [c_long, c_int, c_int, c_int]),
+    "dmn_render_rays": (c_int, [_P, _P, _P, c_long, _P, _P, c_long, c_long, c_int, c_int, _P, _P, c_int, c_int, _P, _P, _P,
+                                _P, _P, _P, _P, _P, _P]),
     "dmn_field_save_floats": (c_long, [c_long]),
     "dmn_field_grad_floats": (c_long, [c_long, c_int]),
     "dmn_field_fwd_rays_save": (c_int, [_P, _P, _P, c_long, c_long, c_int, _P, c_int, _P, _P, _P]),

@@ -103,6 +103,20 @@ int dmn_field_fwd_rays_x3(const float* rays_o, const float* rays_d, const float*
 int dmn_field_fwd_embedded_x3(const float* embedded, long n_points, const void* blob, int ins_num, int precision,
                               float* raw, int* status, void* stream);
 
+/* ---- the whole chunk in one call: dm_nerf (networks/render.py:31-96) ------------------------------------
+ * (stratified jitter with t_rand, or none when NULL ->) coarse field -> compositing -> inverse-CDF resampling
+ * (draws u, or the det = True lattice when NULL) + sorted merge -> fine field -> compositing, all enqueued on
+ * `stream`.  z_coarse is the caller's depth lattice as in the reference's signature (z_vals_coarse).  blobs are
+ * the packed weights of `precision` (dmn_field_pack / dmn_field_pack_x3).  workspace: dmn_render_workspace_floats()
+ * floats laid out [z_coarse n*S | raw_coarse n*S*C | weights_coarse n*S | z_vals_fine n*(S+Ni) | raw_fine n*(S+Ni)*C],
+ * C = 5 + ins_num -- the raw_* / z_vals_* entries of the reference's result dict.  Coarse outputs may be NULL.   */
+long dmn_render_workspace_floats(long n_rays, int n_samples, int n_importance, int ins_num);
+int dmn_render_rays(const float* rays_o, const float* rays_d, const float* z_coarse, long z_ray_stride,
+                    const float* t_rand, const float* u, long u_ray_stride, long n_rays, int n_samples,
+                    int n_importance, const void* blob_coarse, const void* blob_fine, int ins_num, int precision,
+                    float* workspace, float* rgb_fine, float* depth_fine, float* ins_fine, float* rgb_coarse,
+                    float* depth_coarse, float* ins_coarse, int* status, void* stream);
+
 /* ---- training: backward of the field (autograd of networks/dm_nerf.py:80-106 inside train_dmsr.py:32-64) ----
  * The forward writes a save record (register images per 32-point tile: encodings, every layer's output, ReLU
  * sign bits), the backward-data call turns dL/d raw [M,C] into dL/d pre-activation of every layer (gradient

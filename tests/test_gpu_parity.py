@@ -767,6 +767,43 @@ def test_ray_selectors_match_reference_golden(golden):
     assert bool(match.any(1).all()) and int(match.any(0).sum()) == 64
 
 
+# ---- the one-call C entry for a chunk ----------------------------------------------------------------------
+@pytest.mark.parametrize("precision,stochastic", [("fp32", False), ("bf16x3", True)])
+def test_render_rays_entry_point_equals_the_chained_calls(precision, stochastic):
+    """dmn_render_rays (coarse -> composite -> resample -> fine -> composite in one C call) against dm_nerf(), which
+    chains the same kernels from Python: bit-identical, and the workspace holds raw_* / z_vals_fine."""
+    from dm_nerf_amd._lib import load, ptr, current_stream, check
+    n, ins_num = 150, 13
+    o, d, t_rand, u = cases.path_rays(n, seed=41)
+    pos, view, coarse, fine, args = nets(ins_num, 0, 1)
+    args = SimpleNamespace(**{**vars(args), "precision": precision, "perturb": 1.0 if stochastic else 0.0,
+                              "t_rand": G(t_rand), "u": G(u)})
+    z = dm.z_val_sample(n, cases.NEAR, cases.FAR, cases.N_SAMPLES)
+    with torch.no_grad():
+        want = dm.dm_nerf(G(np.stack([o, d], 0)), pos, view, coarse, fine, z, args)
+    lib = load()
+    S, Ni, C = cases.N_SAMPLES, cases.N_IMPORTANCE, 5 + ins_num
+    ws = torch.empty(lib.dmn_render_workspace_floats(n, S, Ni, ins_num), device=DEV)
+    out = {k: torch.empty(n, w, device=DEV) for k, w in (("rgb_fine", 3), ("depth_fine", 1), ("ins_fine", ins_num),
+                                                         ("rgb_coarse", 3), ("depth_coarse", 1), ("ins_coarse", ins_num))}
+    ro, rd = G(o), G(d)
+    zrow = z[:1].contiguous()                                   # the lattice as one shared row (stride 0)
+    tr, uu = (G(t_rand), G(u)) if stochastic else (None, None)
+    check(lib.dmn_render_rays(ptr(ro), ptr(rd), ptr(zrow), 0, ptr(tr), ptr(uu), Ni if stochastic else 0, n, S, Ni,
+                              ptr(coarse.blob(precision)), ptr(fine.blob(precision)), ins_num,
+                              ops.precision_code(precision), ptr(ws), ptr(out["rgb_fine"]), ptr(out["depth_fine"]),
+                              ptr(out["ins_fine"]), ptr(out["rgb_coarse"]), ptr(out["depth_coarse"]),
+                              ptr(out["ins_coarse"]), ptr(ops.status_word(DEV)), current_stream()), "dmn_render_rays")
+    for k, t in out.items():
+        np.testing.assert_array_equal(H(t).reshape(H(want[k]).shape), H(want[k]), err_msg=k)
+    off = n * S
+    np.testing.assert_array_equal(H(ws[off:off + n * S * C]).reshape(n, S, C), H(want["raw_coarse"]))
+    off += n * S * C + n * S
+    np.testing.assert_array_equal(H(ws[off:off + n * (S + Ni)]).reshape(n, S + Ni), H(want["z_vals_fine"]))
+    off += n * (S + Ni)
+    np.testing.assert_array_equal(H(ws[off:off + n * (S + Ni) * C]).reshape(n, S + Ni, C), H(want["raw_fine"]))
+
+
 # ---- error behaviour ------------------------------------------------------------------------------
 def test_errors_are_python_exceptions():
     pos, view, coarse, fine, args = nets(13, 0, 1)

@@ -137,10 +137,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--chunk", type=int, default=16384,
+    ap.add_argument("--chunk", type=int, default=65536,
                     help="rays per dm_nerf call.  The reference's N_test = 4096 bounds memory on small GPUs; it is a "
                          "tiling parameter (results are partition-invariant bit for bit, tests/test_gpu_parity.py), "
-                         "and 16384 saves 1.7 %% of launch ramp on the same device (4096: --chunk 4096)")
+                         "and 65536 saves 2.6 %% of launch ramp and host gaps on the same device (--chunk 4096 for the reference's)")
     ap.add_argument("--cpu-rays", type=int, default=8192, help="rays of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--precision", default=os.environ.get("DMNERF_PRECISION", "bf16x3"),
                     choices=["fp32", "fp16x3", "bf16x3"],

@@ -286,6 +286,20 @@ def main():
                                   "max_abs_rgb_diff_vs_headline_mode": float((rgb32 - rgb).abs().max())}
         args.precision = ns.precision
 
+    if x3 and world == 1 and not ns.no_fp32_leg:
+        # the same image loop with the coarse pass reduced to density (render_image(image_only=True)): identical images,
+        # the coarse network's colour / instance heads are not evaluated.  Reported beside `value`, never as it.
+        only = lambda: dm.render_image(pos, view, coarse, fine, pose, hwk, args, chunk=ns.chunk, image_only=True)
+        rgb_only, _ = only()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        only()
+        torch.cuda.synchronize()
+        dt_only = time.perf_counter() - t1
+        out["image_only_mode"] = {"value": H * W / dt_only, "unit": "rays/s", "ms_per_step": dt_only * 1e3,
+                                  "identical_to_headline_image": bool(torch.equal(rgb_only, rgb)),
+                                  "note": "coarse pass evaluates sigma only; outputs of render_test are unchanged"}
+
     if world == 1 and not ns.no_train_leg:
         out["training_step"] = training_leg(nerf, K, poses[0], device)
 

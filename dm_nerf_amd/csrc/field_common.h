@@ -26,6 +26,7 @@ struct FieldArgs {
   int S;                 // samples per ray (rays mode)
   int ins_ch;            // ins_num + 1
   float* save;           // training: save record per 32-point tile (field_layout.h), or null
+  int sigma_only;        // x3 kernels: stop behind the trunk, raw = [0, 0, 0, sigma, 0...] (coarse pass of an image loop)
 };
 
 // register image access: register `reg` of this wave's tile record (wave-uniform base, one 256-byte row)

@@ -189,6 +189,26 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x3_kernel(const FieldArgs a)
   sigma += __shfl_xor(sigma, 32);
   sigma += cst[kConstDensB];
 
+  if (!SAVE && a.sigma_only) {
+    // Density is all the caller wants (the coarse pass of an image loop only feeds the resampler): skip the colour and
+    // instance branches, 29 % of the network.  The other channels are written as zeros so that raw stays a full row.
+    if (valid) {
+      float* row = a.raw + m * (4 + a.ins_ch);
+      if (h == 0) {
+        row[0] = 0.f; row[1] = 0.f; row[2] = 0.f;
+        row[3] = sigma;
+      }
+#pragma unroll
+      for (int i = 0; i < 16 * T; ++i) {
+        const int ch = feat_of(i, 0) + 4 * h;
+        if (ch < a.ins_ch) row[4 + ch] = 0.f;
+      }
+    }
+    if (P::kCheckRange && a.status != nullptr && !(amax < 60000.f)) atomicOr(a.status, DMN_STATUS_FP16_RANGE);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next stage's LDS-DMA must land before this LDS is released
+    return;
+  }
+
   // ---- rgb_feature_linear (no activation) -> nxt; rgb_feature_linears.0 on [feature, dirs] -> rgb_linear
   layer_x3<P, 8, 16, 0>(c, cst + kConstBias8 + 8 * 256 + h * 128, act_h, act_l, pe_h, pe_l,
                         Lin{nxt_h, nxt_l, &amax, &sigma, dw, false, SAVE ? rec + kSaveFeat * 64 : nullptr, msk});
@@ -310,6 +330,17 @@ extern "C" int dmn_field_fwd_rays_x3(const float* rays_o, const float* rays_d, c
   if (!rays_o || !rays_d || !z || !blob || !raw) return DMN_ERR_BAD_ARG;
   FieldArgs a{rays_o, rays_d, z, z_ray_stride, nullptr, blob, raw, status, n_rays * (long)n_samples, n_samples,
               ins_num + 1, nullptr};
+  return launch_prec(a, ins_num, precision, (hipStream_t)stream);
+}
+
+extern "C" int dmn_field_fwd_rays_x3_sigma(const float* rays_o, const float* rays_d, const float* z, long z_ray_stride,
+                                           long n_rays, int n_samples, const void* blob, int ins_num, int precision,
+                                           float* raw, int* status, void* stream) {
+  if (n_rays < 0 || n_samples <= 0 || ins_num < 0 || z_ray_stride < 0) return DMN_ERR_BAD_ARG;
+  if (n_rays == 0) return DMN_OK;
+  if (!rays_o || !rays_d || !z || !blob || !raw) return DMN_ERR_BAD_ARG;
+  FieldArgs a{rays_o, rays_d, z, z_ray_stride, nullptr, blob, raw, status, n_rays * (long)n_samples, n_samples,
+              ins_num + 1, nullptr, 1};
   return launch_prec(a, ins_num, precision, (hipStream_t)stream);
 }
 

@@ -194,7 +194,11 @@ def encode(x: torch.Tensor, n_freqs: int) -> torch.Tensor:
 
 
 def field_rays(rays_o: torch.Tensor, rays_d: torch.Tensor, z: torch.Tensor, blob: torch.Tensor,
-               ins_num: int, precision: str = "fp32") -> torch.Tensor:
+               ins_num: int, precision: str = "fp32", sigma_only: bool = False) -> torch.Tensor:
+    """raw [N,S,5+ins_num] of the field on ``o + d*z``.  ``sigma_only`` (split-precision kernels): evaluate the trunk
+    and the density head only -- raw[..., 3] is filled, every other channel is zero."""
+    if sigma_only and precision == "fp32":
+        raise ValueError("sigma_only is a mode of the split-precision kernels ('fp16x3' / 'bf16x3')")
     n = rays_o.shape[0]
     rays_o = _dev(rays_o, "rays_o").contiguous()
     rays_d = _dev(rays_d, "rays_d").contiguous()
@@ -206,9 +210,9 @@ def field_rays(rays_o: torch.Tensor, rays_d: torch.Tensor, z: torch.Tensor, blob
             check(load().dmn_field_fwd_rays(ptr(rays_o), ptr(rays_d), ptr(zz), stride, n, s, ptr(blob), ins_num,
                                             ptr(raw), current_stream()), "dmn_field_fwd_rays")
         else:
-            check(load().dmn_field_fwd_rays_x3(ptr(rays_o), ptr(rays_d), ptr(zz), stride, n, s, ptr(blob), ins_num,
-                                               precision_code(precision), ptr(raw), ptr(status_word(raw.device)),
-                                               current_stream()), "dmn_field_fwd_rays_x3")
+            fn = load().dmn_field_fwd_rays_x3_sigma if sigma_only else load().dmn_field_fwd_rays_x3
+            check(fn(ptr(rays_o), ptr(rays_d), ptr(zz), stride, n, s, ptr(blob), ins_num, precision_code(precision),
+                     ptr(raw), ptr(status_word(raw.device)), current_stream()), "dmn_field_fwd_rays_x3")
     return raw
 
 

@@ -56,12 +56,16 @@ def dm_nerf(rays, position_embedder, view_embedder, model_coarse, model_fine, z_
             t_rand = torch.rand(z_vals_coarse.shape, device=rays_d.device)
         z_vals_coarse = ops.jitter_depths(z_vals_coarse, t_rand)                       # render.py:40-47
 
-    def field(model, z):
+    def field(model, z, sigma_only=False):
         if train:       # outputs carry grad to the parameters (SURVEY.md section 8b "Autograd")
             return field_fn().apply(rays_o, rays_d, z, model, precision, *model.parameters())
-        return ops.field_rays(rays_o, rays_d, z, model.blob(precision), model.ins_num, precision)
+        return ops.field_rays(rays_o, rays_d, z, model.blob(precision), model.ins_num, precision, sigma_only=sigma_only)
 
-    raw_coarse = field(model_coarse, z_vals_coarse)
+    # ``args.coarse_heads = False`` (set by render_image(image_only=True), inference in a split precision only): the
+    # coarse network evaluates its trunk and density head only -- raw_coarse[..., 3] and with it the resampling weights
+    # and everything fine are unchanged; rgb_coarse / ins_coarse come out as the composite of zeros.
+    coarse_sigma_only = (not train) and precision != "fp32" and not getattr(args, "coarse_heads", True)
+    raw_coarse = field(model_coarse, z_vals_coarse, coarse_sigma_only)
     rgb_coarse, weights_coarse, depth_coarse, ins_coarse = render_train(raw_coarse, z_vals_coarse, rays_d)
     weights_coarse = weights_coarse.detach()                                            # z_samples.detach(), render.py:68
 

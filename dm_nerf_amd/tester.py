@@ -16,11 +16,14 @@ from .render import dm_nerf
 
 
 def render_image(position_embedder, view_embedder, model_coarse, model_fine, c2w, hwk, args,
-                 chunk: Optional[int] = None, crop_mask=None, ray_range: Optional[Tuple[int, int]] = None):
+                 chunk: Optional[int] = None, crop_mask=None, ray_range: Optional[Tuple[int, int]] = None,
+                 image_only: bool = False):
     """Render one pose.  ``chunk`` defaults to ``args.N_test`` (tester.py:62); the reference's
     O(chunks^2) ``torch.cat`` growth (tester.py:72-76) is replaced by writes into preallocated
     images.  ``ray_range=(a, b)`` renders only flat rays ``[a, b)`` (multi-GPU sharding of one
-    image) and returns flat ``[b-a, .]`` tensors."""
+    image) and returns flat ``[b-a, .]`` tensors.  ``image_only`` (split precisions): the coarse network evaluates
+    its density only -- the colour / instance heads of the coarse pass feed nothing this loop returns
+    (tester.py:70-76 keeps ``rgb_fine`` and ``ins_fine``); the returned images are bit-identical."""
     H, W, K = hwk
     chunk = int(chunk or args.N_test)
     # The image loop defaults to the split-precision field kernel in its bf16 flavour: 7e-6 .. 2e-5 on raw against
@@ -28,8 +31,8 @@ def render_image(position_embedder, view_embedder, model_coarse, model_fine, c2w
     # is ten times closer (1e-6) and 3 % slower; its range guard is checked per image below.
     # dm_nerf() called directly stays on exact fp32 unless args.precision says otherwise.
     precision = getattr(args, "precision", None) or "bf16x3"
-    if getattr(args, "precision", None) != precision:
-        args = SimpleNamespace(**{**vars(args), "precision": precision})
+    if getattr(args, "precision", None) != precision or image_only:
+        args = SimpleNamespace(**{**vars(args), "precision": precision, "coarse_heads": not image_only})
     if precision == "fp16x3":
         ops.take_status(torch.device("cuda", torch.cuda.current_device()))      # clear stale flags
     rays_o, rays_d = get_rays_k(H, W, K, c2w)                                   # tester.py:58
@@ -52,7 +55,7 @@ def render_image(position_embedder, view_embedder, model_coarse, model_fine, c2w
         warnings.warn("dm_nerf_amd: fp16x3 range exceeded, re-rendering this image with precision='fp32'")
         exact = SimpleNamespace(**{**vars(args), "precision": "fp32"})
         return render_image(position_embedder, view_embedder, model_coarse, model_fine, c2w, hwk, exact,
-                            chunk=chunk, crop_mask=crop_mask, ray_range=ray_range)
+                            chunk=chunk, crop_mask=crop_mask, ray_range=ray_range, image_only=image_only)
     if ray_range is not None:
         return rgb, ins
     if crop_mask is not None:                                                    # tester.py:77-81

@@ -102,6 +102,12 @@ int dmn_field_fwd_rays_x3(const float* rays_o, const float* rays_d, const float*
                           void* stream);
 int dmn_field_fwd_embedded_x3(const float* embedded, long n_points, const void* blob, int ins_num, int precision,
                               float* raw, int* status, void* stream);
+/* Density only: the trunk and density_linear (dm_nerf.py:83-87,101), raw[..., 3] = sigma and every other channel 0.
+ * For the coarse pass of an image loop, whose colour / instance outputs nobody reads (networks/tester.py:70-76 keeps
+ * rgb_fine and ins_fine): the compositing weights that drive the resampler depend on sigma alone (render.py:16-18). */
+int dmn_field_fwd_rays_x3_sigma(const float* rays_o, const float* rays_d, const float* z, long z_ray_stride,
+                                long n_rays, int n_samples, const void* blob, int ins_num, int precision, float* raw,
+                                int* status, void* stream);
 
 /* ---- the whole chunk in one call: dm_nerf (networks/render.py:31-96) ------------------------------------
  * (stratified jitter with t_rand, or none when NULL ->) coarse field -> compositing -> inverse-CDF resampling

@@ -767,6 +767,29 @@ def test_ray_selectors_match_reference_golden(golden):
     assert bool(match.any(1).all()) and int(match.any(0).sum()) == 64
 
 
+# ---- image loop with a density-only coarse pass -------------------------------------------------------------
+@pytest.mark.parametrize("precision", ["bf16x3", "fp16x3"])
+def test_image_only_coarse_pass_gives_bit_identical_images(precision):
+    """render_image(image_only=True): the coarse network stops behind its density head; sigma, the resampled depths and
+    both returned images must not change by a bit."""
+    pos, view, coarse, fine, args = nets(13, 0, 1)
+    args.precision = precision
+    Hh, W = 24, 20
+    hwk = [Hh, W, cases.study_intrinsics(Hh, W)]
+    rgb, ins = dm.render_image(pos, view, coarse, fine, cases.study_c2w(), hwk, args, chunk=200)
+    rgb2, ins2 = dm.render_image(pos, view, coarse, fine, cases.study_c2w(), hwk, args, chunk=200, image_only=True)
+    np.testing.assert_array_equal(H(rgb), H(rgb2))
+    np.testing.assert_array_equal(H(ins), H(ins2))
+    o, d, _, _ = cases.path_rays(70, seed=9)
+    z = dm.z_val_sample(70, cases.NEAR, cases.FAR, 64)
+    full = ops.field_rays(G(o), G(d), z, coarse.blob(precision), 13, precision)
+    part = ops.field_rays(G(o), G(d), z, coarse.blob(precision), 13, precision, sigma_only=True)
+    np.testing.assert_array_equal(H(full[..., 3]), H(part[..., 3]))
+    assert float(part[..., :3].abs().max()) == 0.0 and float(part[..., 4:].abs().max()) == 0.0
+    with pytest.raises(ValueError):
+        ops.field_rays(G(o), G(d), z, coarse.blob("fp32"), 13, "fp32", sigma_only=True)
+
+
 # ---- the one-call C entry for a chunk ----------------------------------------------------------------------
 @pytest.mark.parametrize("precision,stochastic", [("fp32", False), ("bf16x3", True)])
 def test_render_rays_entry_point_equals_the_chained_calls(precision, stochastic):

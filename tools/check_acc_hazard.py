@@ -13,7 +13,7 @@ for i0 in starts:
     body = []
     for l in lines[i0 + 1:]:
         s = l.strip()
-        if s.startswith('s_endpgm'):
+        if s.startswith('.Lfunc_end'):
             break
         if s and not s.startswith((';', '.')) and not s.split()[0].endswith(':'):
             body.append(s)

@@ -66,8 +66,8 @@ def host_cores() -> int:
 
 def synthetic_scene(device):
     """Weights and cameras of the synthetic 'study' workload.  The weight tensors come from the
-    oracle module's seeded generator (data only, shared with the parity tests)."""
-    from oracle import dmnerf_cpu as oracle
+    seeded generator in dm_nerf_amd.synthetic (data only, shared with the parity tests)."""
+    from dm_nerf_amd import synthetic as oracle
     args = dm.default_args(ins_num=INS_NUM, N_samples=N_SAMPLES, N_importance=N_IMPORTANCE, N_test=4096,
                            near=4.0, far=15.0, device=device)
     pos, view, coarse, fine, args = dm.create_nerf(args)

@@ -17,7 +17,7 @@ from .manipulator import manipulator_nerf, manipulator_render
 from .penalizer import emptiness_penalizer, ins_penalizer
 from .render import dm_nerf, render_train
 from .tester import render_image, render_test
-from . import autograd, parallel, trainer
+from . import autograd, parallel, synthetic, trainer
 
 # nerf-pytorch names used by BASELINE.json's north_star
 render = dm_nerf

@@ -39,51 +39,10 @@ DIR_CH = 3 + 6 * DIR_FREQS   # 27
 # --------------------------------------------------------------------------------------
 # parameters
 # --------------------------------------------------------------------------------------
-def param_specs(ins_num: int, width: int = NET_WIDTH, depth: int = NET_DEPTH) -> List[Tuple[str, Tuple[int, ...]]]:
-    """Names and shapes of one field network, in the reference's ``state_dict`` order.
-
-    Follows the registration order of ``DM_NeRF.__init__`` (networks/dm_nerf.py:59-78).
-    """
-    specs: List[Tuple[str, Tuple[int, ...]]] = []
-    for i in range(depth):
-        fan_in = POS_CH if i == 0 else (width + POS_CH if i == SKIP_AFTER + 1 else width)
-        specs.append((f"mlps.{i}.weight", (width, fan_in)))
-        specs.append((f"mlps.{i}.bias", (width,)))
-    specs += [
-        ("rgb_feature_linear.weight", (width, width)),
-        ("rgb_feature_linear.bias", (width,)),
-        ("ins_feature_linear.weight", (width, width)),
-        ("ins_feature_linear.bias", (width,)),
-        ("rgb_feature_linears.0.weight", (width // 2, width + DIR_CH)),
-        ("rgb_feature_linears.0.bias", (width // 2,)),
-        ("ins_feature_linears.0.weight", (width // 2, width)),
-        ("ins_feature_linears.0.bias", (width // 2,)),
-        ("density_linear.weight", (1, width)),
-        ("density_linear.bias", (1,)),
-        ("ins_linear.weight", (ins_num + 1, width // 2)),
-        ("ins_linear.bias", (ins_num + 1,)),
-        ("rgb_linear.weight", (3, width // 2)),
-        ("rgb_linear.bias", (3,)),
-    ]
-    return specs
-
-
-def make_params(ins_num: int, seed: int, sharpen: bool = True) -> Params:
-    """Deterministic synthetic weights: PCG64(seed), U(+-1/sqrt(fan_in)) for weight and bias
-    (the distribution of ``nn.Linear``'s default init).  ``sharpen`` scales the
-    density head so that random fields contain opaque structure."""
-    rng = np.random.default_rng(seed)
-    out: Params = {}
-    fan_in = 1
-    for name, shape in param_specs(ins_num):
-        if name.endswith(".weight"):
-            fan_in = shape[1]
-        bound = 1.0 / math.sqrt(fan_in)
-        out[name] = torch.from_numpy(rng.uniform(-bound, bound, size=shape).astype(np.float32))
-    if sharpen:
-        out["density_linear.weight"] = out["density_linear.weight"] * 30.0
-        out["density_linear.bias"] = out["density_linear.bias"] + 0.5
-    return out
+# Seeded synthetic weights (data, not algorithm) come from the product-side generator so that both sides of a parity
+# test build identical tensors from a seed: the oracle may import the product, never the other way round.
+from dm_nerf_amd.synthetic import (dmsr_intrinsics, make_params, param_specs, pose_spherical,   # noqa: E402,F401
+                                   study_pose)
 
 
 # --------------------------------------------------------------------------------------
@@ -344,31 +303,6 @@ def ins_criterion(pred_ins: torch.Tensor, gt_labels: torch.Tensor, ins_num: int)
     invalid_ce = torch.mean(pred_ins[:, rest]) if rest.size else torch.zeros(())       # :29-32
     valid_siou = torch.mean(cost_siou[rows, cols])                                     # :33
     return valid_ce + invalid_ce + valid_siou, valid_ce, invalid_ce, valid_siou
-
-
-def dmsr_intrinsics(H: int, W: int, camera_angle_x: float = 0.6911) -> np.ndarray:
-    f = 0.5 * W / math.tan(0.5 * camera_angle_x)
-    return np.array([[f, 0.0, W / 2.0], [0.0, -f, H / 2.0], [0.0, 0.0, -1.0]], dtype=np.float64)
-
-
-def pose_spherical(theta_deg: float, phi_deg: float, radius: float) -> np.ndarray:
-    """Blender-style orbit pose (datasets/loader_dmsr.py:10-34)."""
-    t = np.eye(4); t[2, 3] = radius
-    p = math.radians(phi_deg)
-    rp = np.array([[1, 0, 0, 0], [0, math.cos(p), -math.sin(p), 0], [0, math.sin(p), math.cos(p), 0], [0, 0, 0, 1.0]])
-    th = math.radians(theta_deg)
-    rt = np.array([[math.cos(th), 0, -math.sin(th), 0], [0, 1, 0, 0], [math.sin(th), 0, math.cos(th), 0], [0, 0, 0, 1.0]])
-    flip = np.array([[-1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1.0]])
-    return (flip @ rt @ rp @ t).astype(np.float32)
-
-
-def study_pose(index: int = 0) -> np.ndarray:
-    """Pose 0 = identity rotation at (0.3,-0.2,6.0); poses 1..7 orbit at phi=-65deg, r=7."""
-    if index == 0:
-        c2w = np.eye(4, dtype=np.float32)
-        c2w[:3, 3] = (0.3, -0.2, 6.0)
-        return c2w
-    return pose_spherical(-180.0 + 45.0 * index, -65.0, 7.0)
 
 
 # --------------------------------------------------------------------------------------

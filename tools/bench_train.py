@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import dm_nerf_amd as dm
 from dm_nerf_amd import trainer
-from oracle import dmnerf_cpu as oracle   # seeded synthetic weights only
+from dm_nerf_amd import synthetic as oracle   # seeded synthetic weights and cameras
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--rays", type=int, default=4096)

@@ -12,7 +12,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dm_nerf_amd as dm  # noqa: E402
 from dm_nerf_amd import ops  # noqa: E402
-from oracle import dmnerf_cpu as oracle  # noqa: E402  (seeded weights only)
+from dm_nerf_amd import synthetic as oracle  # noqa: E402  (seeded weights)
 
 dev = torch.device("cuda", 0)
 m = dm.DM_NeRF(8, 256, 63, 27, [4], 13).to(dev)

@@ -6,7 +6,7 @@ import sys, torch, numpy as np
 sys.path.insert(0, '/root/repo')
 import dm_nerf_amd as dm
 from dm_nerf_amd import ops
-from oracle import dmnerf_cpu as oracle
+from dm_nerf_amd import synthetic as oracle
 dev = torch.device('cuda', 0)
 m = dm.DM_NeRF(8, 256, 63, 27, [4], 13).to(dev)
 m.load_state_dict(oracle.make_params(13, 1))

@@ -351,10 +351,14 @@ __global__ __launch_bounds__(256, 1) void field_wgrad_x3_kernel(const WgArgs a) 
 #pragma unroll
     for (int it = 0; it < NP; ++it) {
       const f32x4 v = stg[it];
-      bf16x4 hi, lo;
-      hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
-      lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
-      lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
+      // packed conversions, and the rounded values back out of the packed words (shift / mask): scalar casts make
+      // the compiler convert every value twice
+      const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      const u32x2 w = __builtin_bit_cast(u32x2, hi);
+      const f32x4 back = {__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
+                          __builtin_bit_cast(float, w.y << 16), __builtin_bit_cast(float, w.y & 0xffff0000u)};
+      const bf16x4 lo = __builtin_convertvector(v - back, bf16x4);
       char* d = lds + (it * 32 + prow) * RB + ppc * 8;
       *reinterpret_cast<bf16x4*>(d) = hi;
       *reinterpret_cast<bf16x4*>(d + R * RB) = lo;

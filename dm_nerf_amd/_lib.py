@@ -47,6 +47,8 @@ SIGNATURES = {
     "dmn_render_workspace_floats": (c_long, [c_long, c_int, c_int, c_int]),
     "dmn_render_rays": (c_int, [_P, _P, _P, c_long, _P, _P, c_long, c_long, c_int, c_int, _P, _P, c_int, c_int, _P, _P, _P,
                                 _P, _P, _P, _P, _P, _P]),
+    "dmn_sigmoid_argmax": (c_int, [_P, c_long, c_long, c_int, _P, _P]),
+    "dmn_exchange": (c_int, [_P, _P, _P, _P, _P, _P, c_long, c_int, c_int, c_int, _P]),
     "dmn_field_save_floats": (c_long, [c_long]),
     "dmn_field_grad_floats": (c_long, [c_long, c_int]),
     "dmn_field_fwd_rays_save": (c_int, [_P, _P, _P, c_long, c_long, c_int, _P, c_int, _P, _P, _P]),

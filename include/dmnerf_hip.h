@@ -123,6 +123,17 @@ int dmn_render_rays(const float* rays_o, const float* rays_d, const float* z_coa
                     float* workspace, float* rgb_fine, float* depth_fine, float* ins_fine, float* rgb_coarse,
                     float* depth_coarse, float* ins_coarse, int* status, void* stream);
 
+/* ---- object manipulation: label surgery between an original and a transformed scene (networks/manipulator.py:18-83)
+ * dmn_sigmoid_argmax: labels[i] = argmax_c sigmoid(x[i*row_stride + c]), c < n_channels, first index among equals
+ *   (torch.argmax(torch.sigmoid(.), -1); per sample point on raw + 4 with n_channels = C - 4, per ray on the
+ *   composited instance map without its last channel).
+ * dmn_exchange: one moved object.  ori_raw [N,S,C] is edited in place (rows taken from tar_raw, or emptied),
+ *   ori_labels [N,S] is updated in place (occluders inherit the ray's label), tar_labels [N,S] is written.       */
+int dmn_sigmoid_argmax(const float* x, long rows, long row_stride, int n_channels, int* labels, void* stream);
+int dmn_exchange(float* ori_raw, const float* tar_raw, int* ori_labels, const int* ori_ray_labels,
+                 const int* tar_ray_labels, int* tar_labels, long n_rays, int n_samples, int channels, int move_label,
+                 void* stream);
+
 /* ---- training: backward of the field (autograd of networks/dm_nerf.py:80-106 inside train_dmsr.py:32-64) ----
  * The forward writes a save record (register images per 32-point tile: encodings, every layer's output, ReLU
  * sign bits), the backward-data call turns dL/d raw [M,C] into dL/d pre-activation of every layer (gradient

@@ -306,6 +306,32 @@ def ins_criterion(pred_ins: torch.Tensor, gt_labels: torch.Tensor, ins_num: int)
 
 
 # --------------------------------------------------------------------------------------
+# object manipulation (row N3) -- restated from the text of networks/manipulator.py:18-83; the module itself
+# does not import in the build image (imageio / cv2 / lpips), so this restatement is NOT pinned by a reference run
+# --------------------------------------------------------------------------------------
+def exchanger(ori_raw: torch.Tensor, tar_raws, ori_raw_pred: torch.Tensor, tar_raw_preds, move_labels):
+    """Label surgery between an original and a transformed scene.  Returns
+    ``(ori_raw_new, tar_raws, ori_pred_label, tar_pred_label_of_last_object)``; unlike the reference the input is
+    not edited in place."""
+    label = lambda x: torch.argmax(torch.sigmoid(x), dim=-1)
+    out = ori_raw.clone()
+    ori_point = label(ori_raw[..., 4:])                                            # :19-21
+    ori_ray = label(ori_raw_pred[..., :-1])[:, None].expand_as(ori_point)          # :23-26
+    tar_point = None
+    for tar_raw, tar_pred, move in zip(tar_raws, tar_raw_preds, move_labels):
+        ori_point = torch.where((ori_point == move) & (ori_ray != move), ori_ray, ori_point)       # :33-36
+        filling = (ori_ray == move) & (ori_point != move)                                          # :40-42
+        tar_point = label(tar_raw[..., 4:])                                                        # :45-48
+        tar_ray = label(tar_pred[..., :-1])[:, None].expand_as(tar_point)                          # :50-53
+        tar_point = torch.where((tar_point == move) & (tar_ray != move), tar_ray, tar_point)       # :57-60
+        take = filling | (tar_point == move)           # operation_mask 1 (target only, or both) and the fillings
+        wipe = (ori_point == move) & (tar_point != move)                                           # operation_mask 0
+        out = torch.where(take[..., None], tar_raw, out)                                           # :78-80
+        out = torch.where(wipe[..., None], out * 0, out)                                           # :81
+    return out, tar_raws, ori_point, tar_point
+
+
+# --------------------------------------------------------------------------------------
 # training ray selectors (SURVEY.md section 8f, row N1)
 # --------------------------------------------------------------------------------------
 def select_full(rgb: torch.Tensor, pose: torch.Tensor, K, labels: torch.Tensor, picked) -> Tuple:

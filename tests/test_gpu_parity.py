@@ -790,6 +790,58 @@ def test_image_only_coarse_pass_gives_bit_identical_images(precision):
         ops.field_rays(G(o), G(d), z, coarse.blob("fp32"), 13, "fp32", sigma_only=True)
 
 
+# ---- object manipulation (row N3) ---------------------------------------------------------------------------
+def test_exchanger_matches_the_restated_label_surgery():
+    """exchanger() against the oracle's restatement of networks/manipulator.py:18-83 (the reference module does not
+    import here: unpinned).  Two moved objects, labels biased so that every branch occurs: occluders, fillings, take,
+    wipe, keep; saturated logits so that the sigmoid's ties matter."""
+    rng = np.random.default_rng(55)
+    n, s, c = 48, 64, 18
+    def scene(seed_shift):
+        raw = (rng.standard_normal((n, s, c)) * 3).astype(np.float32)
+        for lab in (3, 7):
+            hit = rng.random((n, s)) < 0.2
+            raw[hit, 4 + lab] += 9.0
+        raw[0, :8, 4:] = 40.0                                   # all logits saturate: argmax(sigmoid) = first channel
+        pred = (rng.standard_normal((n, c - 4)) * 3).astype(np.float32)
+        pred[rng.random(n) < 0.3, 3] += 9.0
+        pred[rng.random(n) < 0.3, 7] += 9.0
+        return raw, pred
+    ori_raw, ori_pred = scene(0)
+    tars = [scene(1), scene(2)]
+    moves = [3, 7]
+    want_raw, _, want_ol, want_tl = oracle.exchanger(torch.from_numpy(ori_raw), [torch.from_numpy(t[0]) for t in tars],
+                                                     torch.from_numpy(ori_pred), [torch.from_numpy(t[1]) for t in tars],
+                                                     moves)
+    got = G(ori_raw)
+    out_raw, _, ol, tl = dm.exchanger(got, [G(t[0]) for t in tars], G(ori_pred), [G(t[1]) for t in tars], moves)
+    assert out_raw.data_ptr() == got.data_ptr()                 # edited in place, like the reference
+    np.testing.assert_array_equal(H(ol), want_ol.numpy())
+    np.testing.assert_array_equal(H(tl), want_tl.numpy())
+    np.testing.assert_array_equal(H(out_raw), want_raw.numpy())
+    changed = (want_raw.numpy() != ori_raw).any(-1)
+    wiped = (want_raw.numpy() == 0).all(-1)
+    assert 0.05 < changed.mean() < 0.95 and wiped.any() and (changed & ~wiped).any()
+
+
+def test_manipulator_two_pass_rerender_runs_on_the_kernels():
+    """manipulator() (networks/manipulator.py:136-205): identity 'move' of an object must reproduce the plain
+    re-render wherever labels agree; here: shapes, finiteness and determinism under fixed draws."""
+    pos, view, coarse, fine, args = nets(13, 0, 1)
+    o, d, _, _ = cases.path_rays(40, seed=61)
+    rays = G(np.stack([o, d], 0))
+    shifted = torch.stack([rays[0] + torch.tensor([0.3, 0.0, 0.0], device=DEV), rays[1]], 0)
+    margs = SimpleNamespace(N_samples=64, N_importance=128, near=cases.NEAR, far=cases.FAR, target_label=[2])
+    torch.manual_seed(5)
+    rgb, ins, tar_rgb, tar_acc = dm.manipulator(pos, view, coarse, fine, rays, [shifted], margs)
+    assert rgb.shape == (40, 3) and ins.shape == (40, 14) and tar_rgb.shape == (40, 3) and tar_acc.shape == (40, 14)
+    assert all(np.isfinite(H(t)).all() for t in (rgb, ins, tar_rgb, tar_acc))
+    torch.manual_seed(5)
+    rgb2, ins2, _, _ = dm.manipulator(pos, view, coarse, fine, rays, [shifted], margs)
+    np.testing.assert_array_equal(H(rgb), H(rgb2))
+    np.testing.assert_array_equal(H(ins), H(ins2))
+
+
 # ---- the one-call C entry for a chunk ----------------------------------------------------------------------
 @pytest.mark.parametrize("precision,stochastic", [("fp32", False), ("bf16x3", True)])
 def test_render_rays_entry_point_equals_the_chained_calls(precision, stochastic):

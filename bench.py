@@ -64,12 +64,12 @@ def host_cores() -> int:
     return max(1, min(n, 16))
 
 
-def synthetic_scene(device):
+def synthetic_scene(device, near=4.0, far=15.0):
     """Weights and cameras of the synthetic 'study' workload.  The weight tensors come from the
     seeded generator in dm_nerf_amd.synthetic (data only, shared with the parity tests)."""
     from dm_nerf_amd import synthetic as oracle
     args = dm.default_args(ins_num=INS_NUM, N_samples=N_SAMPLES, N_importance=N_IMPORTANCE, N_test=4096,
-                           near=4.0, far=15.0, device=device)
+                           near=near, far=far, device=device)
     pos, view, coarse, fine, args = dm.create_nerf(args)
     params = oracle.make_params(INS_NUM, 0), oracle.make_params(INS_NUM, 1)
     coarse.load_state_dict(params[0])
@@ -79,16 +79,16 @@ def synthetic_scene(device):
     return (pos, view, coarse.eval(), fine.eval(), args), K, poses, params
 
 
-def cpu_baseline(K, pose, params, sample_rays: int, chunk: int):
+def cpu_baseline(K, pose, params, sample_rays: int, chunk: int, near: float = 4.0, far: float = 15.0):
     """The CPU oracle (port of the reference's PyTorch-CPU path) on a bounded sample of the same
     workload: the first `sample_rays` rays of the image in `chunk`-ray pieces, after one warm-up."""
     from oracle import dmnerf_cpu as oracle
     torch.set_num_threads(host_cores())
     c2w = torch.from_numpy(pose)
-    oracle.render_image(H, W, K, c2w, params[0], params[1], 4.0, 15.0, N_SAMPLES, N_IMPORTANCE, chunk=256,
+    oracle.render_image(H, W, K, c2w, params[0], params[1], near, far, N_SAMPLES, N_IMPORTANCE, chunk=256,
                         max_rays=256)
     t0 = time.perf_counter()
-    rgb, ins = oracle.render_image(H, W, K, c2w, params[0], params[1], 4.0, 15.0, N_SAMPLES, N_IMPORTANCE,
+    rgb, ins = oracle.render_image(H, W, K, c2w, params[0], params[1], near, far, N_SAMPLES, N_IMPORTANCE,
                                    chunk=chunk, max_rays=sample_rays)
     dt = time.perf_counter() - t0
     return sample_rays / dt, rgb, ins
@@ -146,11 +146,21 @@ def main():
                     choices=["fp32", "fp16x3", "bf16x3"],
                     help="field-kernel arithmetic: fp32 = exact fp32 MFMA; fp16x3 / bf16x3 = three 16-bit MFMAs "
                          "per product (hi/lo split, fp32 accumulate)")
+    ap.add_argument("--workload", default="study", choices=["study", "replica"],
+                    help="study = BASELINE config 2 (the headline: DM-SR 'study' 800x800, ins_num 13); replica = config 3 "
+                         "shape (room_0: 640x480, ins_num 93, near 0 / far 6.5) for a side measurement")
     ap.add_argument("--no-train-leg", action="store_true",
                     help="skip the extra training-step measurement after the timed region (N = 1 only)")
     ap.add_argument("--no-fp32-leg", action="store_true",
                     help="skip the extra 2 images rendered in exact-fp32 mode after the timed region (N = 1 only)")
     ns = ap.parse_args()
+
+    global H, W, INS_NUM, MACS_PER_POINT, FLOP_PER_POINT
+    near, far, scene = 4.0, 15.0, "DM-SR 'study' 800x800"
+    if ns.workload == "replica":            # configs/train/replica/room_0.txt:13-14, loader_replica.py
+        H, W, INS_NUM, near, far, scene = 480, 640, 93, 0.0, 6.5, "Replica room_0 shape 640x480"
+        MACS_PER_POINT = 693_504 + (93 - 13) * 129          # ins_linear grows by 80 rows of 128 weights + bias
+        FLOP_PER_POINT = 2 * MACS_PER_POINT
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -174,7 +184,7 @@ def main():
             dist.init_process_group(backend=backend)
 
     dm.load_library()
-    nerf, K, poses, params = synthetic_scene(device)
+    nerf, K, poses, params = synthetic_scene(device, near, far)
     pos, view, coarse, fine, args = nerf
     args.precision = ns.precision
     pose = poses[rank % len(poses)]
@@ -232,14 +242,15 @@ def main():
     comp_gbs = comp_bytes / t_c / 1e9
 
     out = {
-        "metric": "rays/sec, DM-SR study 800x800, 64+128 samples (PSNR vs reference path in `psnr_vs_cpu_oracle_db`)",
+        "metric": f"rays/sec, {'DM-SR study 800x800' if ns.workload == 'study' else scene}, 64+128 samples (PSNR vs "
+                  "reference path in `psnr_vs_cpu_oracle_db`)",
         "value": value, "unit": "rays/s", "n_gpus": world, "steps": ns.steps, "warmup": ns.warmup,
         "ms_per_step": elapsed / ns.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": {"fp32": "f32", "fp16x3": "f16x3 (hi/lo split, f32 accumulate)",
                                        "bf16x3": "bf16x3 (hi/lo split, f32 accumulate)"}[ns.precision],
         "data": "synthetic",
-        "config": {"workload": "DM-SR 'study' 800x800, 64+128 hierarchical, 8x256 field, RGB+sigma+instance head "
-                               "(ins_num=13), 1 image per GPU per step", "chunk_rays": ns.chunk,
+        "config": {"workload": f"{scene}, 64+128 hierarchical, 8x256 field, RGB+sigma+instance head "
+                               f"(ins_num={INS_NUM}), 1 image per GPU per step", "chunk_rays": ns.chunk,
                    "precision": ns.precision, "parallelism": f"ray/image-sharded x{world}, no collective"},
         "roofline": {"kernel": kernel_name, "bound": "mfma",
                      "achieved": field_tflops, "peak": peak, "unit": "TFLOP/s",
@@ -304,7 +315,7 @@ def main():
         out["training_step"] = training_leg(nerf, K, poses[0], device)
 
     if ns.cpu_rays > 0 and world == 1:       # the CPU baseline is timed on rank 0 at N = 1 only
-        cpu_rps, cpu_rgb, cpu_ins = cpu_baseline(K, pose, params, ns.cpu_rays, CPU_CHUNK)
+        cpu_rps, cpu_rgb, cpu_ins = cpu_baseline(K, pose, params, ns.cpu_rays, CPU_CHUNK, near, far)
         got = rgb.reshape(-1, 3)[: ns.cpu_rays].cpu()
         mse = float(torch.mean((got - cpu_rgb) ** 2))
         out["psnr_vs_cpu_oracle_db"] = float(-10.0 * np.log10(max(mse, 1e-20)))

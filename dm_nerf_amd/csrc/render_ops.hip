@@ -169,13 +169,15 @@ struct CompositeArgs {
   float* ins;
 };
 
+constexpr int kWideChannels = 32;   // above this many raw channels the channel sums walk the samples (see below)
+
 __global__ __launch_bounds__(64 * kWavesPerBlock) void composite_kernel(CompositeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int C = a.C, S = a.S;
   float* slab = smem + (long)wave * 64 * C;
-  const long n = (long)blockIdx.x * kWavesPerBlock + wave;
+  const long n = (long)blockIdx.x * (blockDim.x >> 6) + wave;   // 4 rays per block, 1 when the slabs are large
   const bool ray_ok = n < a.n_rays;
   const long nc = ray_ok ? n : a.n_rays - 1;
 
@@ -225,16 +227,39 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void composite_kernel(Composit
 
     // channel sums: rgb through sigmoid (render.py:14,19), channel 3 carries depth (render.py:20),
     // instance logits raw (render.py:24)
+    if (C <= kWideChannels) {
+      // few channels: lane = sample, one wave reduction per channel
 #pragma unroll
-    for (int cb = 0; cb < 3; ++cb) {
-      const int cend = min(C - cb * 64, 64);
-      for (int cc = 0; cc < cend; ++cc) {
-        const int c = cb * 64 + cc;
-        float v = ok ? slab[lane * C + c] : 0.f;
-        if (c < 3) v = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-v)));
-        if (c == 3) v = zc;
-        v = wave_sum(__fmul_rn(w, v));
-        if (lane == cc) tot[cb] += v;
+      for (int cb = 0; cb < 3; ++cb) {
+        const int cend = min(C - cb * 64, 64);
+        for (int cc = 0; cc < cend; ++cc) {
+          const int c = cb * 64 + cc;
+          float v = ok ? slab[lane * C + c] : 0.f;
+          if (c < 3) v = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-v)));
+          if (c == 3) v = zc;
+          v = wave_sum(__fmul_rn(w, v));
+          if (lane == cc) tot[cb] += v;
+        }
+      }
+    } else {
+      // many channels (Replica / ScanNet: ~100): lane = channel, a walk over the slab's samples -- rows of the slab are
+      // read contiguously and one fma replaces a 64-lane reduction per channel; the weights and depths of the samples
+      // are passed through the (already consumed) sigma column of the slab
+      if (ok) {
+        slab[lane * C + 3] = zc;
+        slab[lane * C + 0] = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-slab[lane * C + 0])));
+        slab[lane * C + 1] = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-slab[lane * C + 1])));
+        slab[lane * C + 2] = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-slab[lane * C + 2])));
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (int sidx = 0; sidx < cnt; ++sidx) {
+        const float ws = __shfl(w, sidx);
+#pragma unroll
+        for (int cb = 0; cb < 3; ++cb) {
+          const int c = cb * 64 + lane;
+          if (c < C) tot[cb] = fmaf(ws, slab[sidx * C + c], tot[cb]);
+        }
       }
     }
   }
@@ -518,16 +543,19 @@ extern "C" int dmn_composite_fwd(const float* raw, const float* z, long z_ray_st
   if (n_rays == 0) return DMN_OK;
   if (!raw || !z || !rays_d) return DMN_ERR_BAD_ARG;
   if (channels > 192) return DMN_ERR_UNSUPPORTED;
-  const size_t lds = (size_t)kWavesPerBlock * 64 * channels * sizeof(float);
+  // With ~100 channels a 64-sample slab is 25 KB: one ray per block then lets six independent blocks share a CU, so
+  // that one ray's slab load overlaps another's arithmetic (four rays per block would be one block per CU, all four
+  // waves loading and computing in lockstep).
+  const int wpb = channels > kWideChannels ? 1 : kWavesPerBlock;
+  const size_t lds = (size_t)wpb * 64 * channels * sizeof(float);
   if (lds > kMaxLds) return DMN_ERR_UNSUPPORTED;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute((const void*)composite_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
           hipSuccess)
     return DMN_ERR_LAUNCH;
   CompositeArgs a{raw, z, z_ray_stride, rays_d, n_rays, n_samples, channels, keep_last, rgb, weights, depth, ins};
-  const long blocks = (n_rays + kWavesPerBlock - 1) / kWavesPerBlock;
-  hipLaunchKernelGGL(composite_kernel, dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, (hipStream_t)stream,
-                     a);
+  const long blocks = (n_rays + wpb - 1) / wpb;
+  hipLaunchKernelGGL(composite_kernel, dim3((unsigned)blocks), dim3(64 * wpb), lds, (hipStream_t)stream, a);
   return launch_status();
 }
 

@@ -5,7 +5,7 @@ Unlike the reference module, importing this file has no global side effect (the 
 switches on autograd anomaly detection at import, networks/dm_nerf.py:5)."""
 from __future__ import annotations
 
-from typing import List, Optional, Tuple
+from typing import List
 
 import torch
 import torch.nn as nn

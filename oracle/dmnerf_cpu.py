@@ -18,8 +18,7 @@ module is a fair stand-in for the reference's PyTorch-CPU path.
 """
 from __future__ import annotations
 
-import math
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, Optional, Tuple
 
 import numpy as np
 import torch

@@ -3,12 +3,11 @@ the weight-gradient scatter table and the transposed-weight blobs of the backwar
 themselves are checked on the GPU (tests/test_gpu_parity.py)."""
 import numpy as np
 import pytest
-import torch
 
 from oracle import dmnerf_cpu as oracle
 
 import dm_nerf_amd
-from test_layout import CONST, CHUNK, STAGE, X3_CHUNK, HALF, P, Wave, feat_of, pos_slot
+from test_layout import CONST, CHUNK, STAGE, X3_CHUNK, HALF, P, feat_of, pos_slot
 
 # save / gradient record register offsets (field_layout.h)
 SAVE_PE, SAVE_QE, SAVE_H, SAVE_FEAT, SAVE_R1, SAVE_INSF, SAVE_I1 = 0, 32, 48, 1072, 1200, 1264, 1392

@@ -6,8 +6,6 @@ the weight stream exactly the way the fused kernel does: activations as the B op
 from the accumulator registers, weights as the A operand from 1 KiB chunks.  The result must equal
 the oracle's field network.  This pins the layout logic on CPU; the kernel itself is checked on
 the GPU (tests/test_gpu_parity.py)."""
-import ctypes
-
 import numpy as np
 import pytest
 import torch

@@ -5,7 +5,6 @@ values to 1e-5 (CPU GEMM blocking depends on the batch shape; on the GPU the HIP
 partition-invariant bit for bit, tests/test_gpu_parity.py::test_full_size_chunk_properties)."""
 import os
 import socket
-import sys
 
 import numpy as np
 import pytest

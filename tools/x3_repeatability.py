@@ -2,7 +2,7 @@
 """Repeatability probe of the split-precision field kernels: several shapes, three launches each, error against the
 exact kernel.  Differences between repetitions mean a race or an uncovered hardware hazard (this is how the
 inline-asm accumulator-read hazard showed up: 7e-2 errors that changed from run to run)."""
-import sys, torch, numpy as np
+import sys, torch
 sys.path.insert(0, '/root/repo')
 import dm_nerf_amd as dm
 from dm_nerf_amd import ops

@@ -169,7 +169,7 @@ struct CompositeArgs {
   float* ins;
 };
 
-constexpr int kWideChannels = 32;   // above this many raw channels the channel sums walk the samples (see below)
+constexpr int kWideChannels = 32;   // wider raw rows are composited by composite_wide_kernel (no LDS slab)
 
 __global__ __launch_bounds__(64 * kWavesPerBlock) void composite_kernel(CompositeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void composite_kernel(Composit
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int C = a.C, S = a.S;
   float* slab = smem + (long)wave * 64 * C;
-  const long n = (long)blockIdx.x * (blockDim.x >> 6) + wave;   // 4 rays per block, 1 when the slabs are large
+  const long n = (long)blockIdx.x * kWavesPerBlock + wave;
   const bool ray_ok = n < a.n_rays;
   const long nc = ray_ok ? n : a.n_rays - 1;
 
@@ -227,39 +227,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void composite_kernel(Composit
 
     // channel sums: rgb through sigmoid (render.py:14,19), channel 3 carries depth (render.py:20),
     // instance logits raw (render.py:24)
-    if (C <= kWideChannels) {
-      // few channels: lane = sample, one wave reduction per channel
+    // lane = sample, one wave reduction per channel (rows of up to kWideChannels channels; wider rows go to
+    // composite_wide_kernel)
 #pragma unroll
-      for (int cb = 0; cb < 3; ++cb) {
-        const int cend = min(C - cb * 64, 64);
-        for (int cc = 0; cc < cend; ++cc) {
-          const int c = cb * 64 + cc;
-          float v = ok ? slab[lane * C + c] : 0.f;
-          if (c < 3) v = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-v)));
-          if (c == 3) v = zc;
-          v = wave_sum(__fmul_rn(w, v));
-          if (lane == cc) tot[cb] += v;
-        }
-      }
-    } else {
-      // many channels (Replica / ScanNet: ~100): lane = channel, a walk over the slab's samples -- rows of the slab are
-      // read contiguously and one fma replaces a 64-lane reduction per channel; the weights and depths of the samples
-      // are passed through the (already consumed) sigma column of the slab
-      if (ok) {
-        slab[lane * C + 3] = zc;
-        slab[lane * C + 0] = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-slab[lane * C + 0])));
-        slab[lane * C + 1] = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-slab[lane * C + 1])));
-        slab[lane * C + 2] = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-slab[lane * C + 2])));
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      for (int sidx = 0; sidx < cnt; ++sidx) {
-        const float ws = __shfl(w, sidx);
-#pragma unroll
-        for (int cb = 0; cb < 3; ++cb) {
-          const int c = cb * 64 + lane;
-          if (c < C) tot[cb] = fmaf(ws, slab[sidx * C + c], tot[cb]);
-        }
+    for (int cb = 0; cb < 3; ++cb) {
+      const int cend = min(C - cb * 64, 64);
+      for (int cc = 0; cc < cend; ++cc) {
+        const int c = cb * 64 + cc;
+        float v = ok ? slab[lane * C + c] : 0.f;
+        if (c < 3) v = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-v)));
+        if (c == 3) v = zc;
+        v = wave_sum(__fmul_rn(w, v));
+        if (lane == cc) tot[cb] += v;
       }
     }
   }
@@ -276,6 +255,78 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void composite_kernel(Composit
       if (a.depth) a.depth[n] = tot[cb];
     } else if (c - 4 < K) {
       // ins_map = sigmoid(sum w * logits)   (render.py:24-26)
+      if (a.ins) a.ins[n * K + (c - 4)] = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-tot[cb])));
+    }
+  }
+}
+
+// Compositing for wide rows (C > kWideChannels; Replica / ScanNet carry ~100 channels): no LDS slab.  Lane = sample
+// reads only the density column for the transmittance scan; then the lanes turn to channels (lane l owns channels
+// l, 64 + l, 128 + l) and walk the slab's samples with rows read straight from global memory -- every row is one
+// contiguous wave access, each raw byte comes from HBM once (the density column's lines are met again in L2), and
+// without a 25 KB slab per ray the occupancy is no longer set by LDS.  Same arithmetic as composite_kernel's walk.
+__global__ __launch_bounds__(64 * kWavesPerBlock) void composite_wide_kernel(CompositeArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int C = a.C, S = a.S;
+  const long n = (long)blockIdx.x * kWavesPerBlock + wave;
+  if (n >= a.n_rays) return;                        // no block-level synchronisation in this kernel
+
+  const float dx = a.rays_d[3 * n + 0], dy = a.rays_d[3 * n + 1], dz = a.rays_d[3 * n + 2];
+  const float norm = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+  const float* zr = a.z + n * a.zs;
+  const float* rawr = a.raw + n * (long)S * C;
+
+  float tot[3] = {0.f, 0.f, 0.f};
+  double carry = 1.0;
+  for (int s0 = 0; s0 < S; s0 += 64) {
+    const int cnt = min(64, S - s0);
+    const int s = s0 + lane;
+    const bool ok = lane < cnt;
+    const float zc = ok ? zr[s] : 0.f;
+    float delta = 1e10f;
+    if (ok && s + 1 < S) delta = __fsub_rn(zr[s + 1], zc);
+    delta = __fmul_rn(delta, norm);
+    const float sigma = ok ? rawr[(long)s * C + 3] : 0.f;
+    const float alpha = ok ? __fsub_rn(1.f, expf(-__fmul_rn(fmaxf(sigma, 0.f), delta))) : 0.f;
+    const double f = ok ? (double)__fadd_rn(__fsub_rn(1.f, alpha), 1e-10f) : 1.0;
+    const double incl = wave_scan<true>(f, lane);
+    double excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = 1.0;
+    const float T = (float)(carry * excl);
+    carry = carry * __shfl(incl, 63);
+    const float w = ok ? __fmul_rn(alpha, T) : 0.f;
+    if (ok && a.weights) a.weights[n * S + s] = w;
+
+    const float* row = rawr + (long)s0 * C;
+#pragma unroll 8
+    for (int sidx = 0; sidx < cnt; ++sidx, row += C) {
+      const float ws = __shfl(w, sidx), zs = __shfl(zc, sidx);
+#pragma unroll
+      for (int cb = 0; cb < 3; ++cb) {
+        const int c = cb * 64 + lane;
+        if (c < C) {
+          float v = row[c];
+          if (cb == 0) {
+            if (lane < 3) v = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-v)));
+            if (lane == 3) v = zs;
+          }
+          tot[cb] = fmaf(ws, v, tot[cb]);
+        }
+      }
+    }
+  }
+
+  const int K = a.keep_last ? C - 4 : C - 5;
+#pragma unroll
+  for (int cb = 0; cb < 3; ++cb) {
+    const int c = cb * 64 + lane;
+    if (c >= C) continue;
+    if (c < 3) {
+      if (a.rgb) a.rgb[3 * n + c] = tot[cb];
+    } else if (c == 3) {
+      if (a.depth) a.depth[n] = tot[cb];
+    } else if (c - 4 < K) {
       if (a.ins) a.ins[n * K + (c - 4)] = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-tot[cb])));
     }
   }
@@ -446,8 +497,6 @@ inline unsigned ew_blocks(long total) {
   return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
 }
 
-constexpr size_t kMaxLds = 160 * 1024;
-
 }  // namespace
 
 // ==========================================================================================
@@ -543,19 +592,16 @@ extern "C" int dmn_composite_fwd(const float* raw, const float* z, long z_ray_st
   if (n_rays == 0) return DMN_OK;
   if (!raw || !z || !rays_d) return DMN_ERR_BAD_ARG;
   if (channels > 192) return DMN_ERR_UNSUPPORTED;
-  // With ~100 channels a 64-sample slab is 25 KB: one ray per block then lets six independent blocks share a CU, so
-  // that one ray's slab load overlaps another's arithmetic (four rays per block would be one block per CU, all four
-  // waves loading and computing in lockstep).
-  const int wpb = channels > kWideChannels ? 1 : kWavesPerBlock;
-  const size_t lds = (size_t)wpb * 64 * channels * sizeof(float);
-  if (lds > kMaxLds) return DMN_ERR_UNSUPPORTED;
-  if (lds > 64 * 1024 &&
-      hipFuncSetAttribute((const void*)composite_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-          hipSuccess)
-    return DMN_ERR_LAUNCH;
   CompositeArgs a{raw, z, z_ray_stride, rays_d, n_rays, n_samples, channels, keep_last, rgb, weights, depth, ins};
-  const long blocks = (n_rays + wpb - 1) / wpb;
-  hipLaunchKernelGGL(composite_kernel, dim3((unsigned)blocks), dim3(64 * wpb), lds, (hipStream_t)stream, a);
+  const long blocks = (n_rays + kWavesPerBlock - 1) / kWavesPerBlock;
+  if (channels > kWideChannels) {          // wide rows: straight from global memory, no LDS slab
+    hipLaunchKernelGGL(composite_wide_kernel, dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), 0,
+                       (hipStream_t)stream, a);
+    return launch_status();
+  }
+  const size_t lds = (size_t)kWavesPerBlock * 64 * channels * sizeof(float);
+  hipLaunchKernelGGL(composite_kernel, dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds, (hipStream_t)stream,
+                     a);
   return launch_status();
 }
 

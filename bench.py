@@ -7,6 +7,9 @@ HIP hot path, plus the roofline of the dominant kernel and the CPU oracle timed 
 
 One step = one full 800x800 image (640,000 rays) rendered through ``dm_nerf_amd.render_image``
 (ray generation -> per chunk: coarse field, composite, resample+merge, fine field, composite).
+``value`` is measured in the reference's arithmetic (``--precision fp32``: exact fp32 MFMA products); the
+split-precision modes (three 16-bit MFMAs per product) are timed over the same --steps right after it and reported
+beside it (``split_precision_modes``) with their deviation statistics against the CPU oracle.
 Inputs are synthetic (no dataset / checkpoint exists offline): DM-SR style intrinsics, orbit
 poses, PCG64-seeded weights.  With N > 1 (launched by torch.distributed.run,
 one process per GPU) every rank renders its own pose: no data-path collective, weak scaling.
@@ -79,21 +82,6 @@ def synthetic_scene(device, near=4.0, far=15.0):
     return (pos, view, coarse.eval(), fine.eval(), args), K, poses, params
 
 
-def cpu_baseline(K, pose, params, sample_rays: int, chunk: int, near: float = 4.0, far: float = 15.0):
-    """The CPU oracle (port of the reference's PyTorch-CPU path) on a bounded sample of the same
-    workload: the first `sample_rays` rays of the image in `chunk`-ray pieces, after one warm-up."""
-    from oracle import dmnerf_cpu as oracle
-    torch.set_num_threads(host_cores())
-    c2w = torch.from_numpy(pose)
-    oracle.render_image(H, W, K, c2w, params[0], params[1], near, far, N_SAMPLES, N_IMPORTANCE, chunk=256,
-                        max_rays=256)
-    t0 = time.perf_counter()
-    rgb, ins = oracle.render_image(H, W, K, c2w, params[0], params[1], near, far, N_SAMPLES, N_IMPORTANCE,
-                                   chunk=chunk, max_rays=sample_rays)
-    dt = time.perf_counter() - t0
-    return sample_rays / dt, rgb, ins
-
-
 def training_leg(nerf, K, pose, device, n_rays: int = 4096, steps: int = 4):
     """BASELINE config 4 on one GPU, outside the timed region: `steps` optimisation steps of `n_rays` random rays of
     the same camera (stochastic path, colour + instance-matching + emptiness losses, Adam), hand-written forward and
@@ -132,6 +120,98 @@ def training_leg(nerf, K, pose, device, n_rays: int = 4096, steps: int = 4):
     return result
 
 
+def timed_images(step, steps: int, warmup: int, barrier):
+    """`warmup` untimed images, then exactly `steps` images bracketed by barrier + synchronize; per-launch HIP events
+    (recorded on the launch stream by ops._timed) are collected over the timed region."""
+    for _ in range(warmup):
+        step()
+    barrier()
+    ops.PROFILE = []
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    profile, ops.PROFILE = ops.PROFILE, None
+    return elapsed, profile, out
+
+
+def kernel_stats(profile, name):
+    rows = [(a.elapsed_time(b) * 1e-3, work) for k, a, b, work in profile if k == name]
+    return len(rows), float(sum(r[0] for r in rows)), int(sum(r[1] for r in rows))
+
+
+def field_roofline(profile, precision: str, elapsed: float):
+    """Roofline object of the field kernel from the HIP events of one timed region."""
+    n_f, t_f, pts_f = kernel_stats(profile, "field_fwd")
+    tflops = pts_f * FLOP_PER_POINT / t_f / 1e12
+    x3 = precision != "fp32"
+    peak = PEAK_16BIT_MFMA_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS
+    name = (f"field_fwd_x3_kernel<{precision}> (fused encodings + 8x256 field; every fp32 product = 3 16-bit MFMA "
+            "products on hi/lo splits, fp32 accumulate)" if x3 else
+            "field_fwd_kernel<1> (fused encodings + 8x256 field, exact fp32 MFMA v_mfma_f32_32x32x2_f32)")
+    return {"kernel": name, "bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak,
+            "traffic": None, "mfma_flop_issued_per_algorithmic_flop": 3 if x3 else 1, "launches": n_f,
+            "avg_launch_ms": t_f / max(n_f, 1) * 1e3,
+            "algorithmic_flop_per_launch": pts_f * FLOP_PER_POINT / max(n_f, 1), "time_share_of_step": t_f / elapsed,
+            # nominal peak is at 2.4 GHz; with every CU on 16-bit MFMA the board power limit holds the clock lower:
+            # tools/mfma_peak.hip, profiles/r02a_mfma_shapes.txt
+            "peak_sustained_measured": SUSTAINED_MFMA_TFLOPS[precision],
+            "mfma_issue_frac_of_sustained": (3 if x3 else 1) * tflops / SUSTAINED_MFMA_TFLOPS[precision]}
+
+
+def deviation_stats(got: torch.Tensor, want: torch.Tensor):
+    """Per-ray worst deviation relative to max|want| (the north-star's 'relative'): fraction of rays beyond 1e-4,
+    99.9th percentile and maximum."""
+    got, want = got.double().reshape(got.shape[0], -1), want.double().reshape(want.shape[0], -1)
+    per_ray = (got - want).abs().max(-1).values / want.abs().max().clamp_min(1e-30)
+    return {"frac_rays_over_1e-4": float((per_ray > 1e-4).double().mean()),
+            "p99.9": float(torch.quantile(per_ray, 0.999)), "max": float(per_ray.max())}
+
+
+def sample_outputs(nerf, K, pose, precision: str, n_rays: int, chunk: int):
+    """rgb_fine / depth_fine / ins_fine of the first `n_rays` rays of the image in `chunk`-ray dm_nerf calls."""
+    from types import SimpleNamespace
+    pos, view, coarse, fine, args = nerf
+    args = SimpleNamespace(**{**vars(args), "precision": precision})
+    ro, rd = dm.get_rays_k(H, W, K, pose)
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    outs = {"rgb_fine": [], "depth_fine": [], "ins_fine": []}
+    with torch.no_grad():
+        for s in range(0, n_rays, chunk):
+            n = min(chunk, n_rays - s)
+            z = dm.z_val_sample(n, args.near, args.far, args.N_samples)
+            r = dm.dm_nerf(torch.stack([ro[s:s + n], rd[s:s + n]], 0), pos, view, coarse, fine, z, args)
+            for k in outs:
+                outs[k].append(r[k])
+    return {k: torch.cat(v, 0).cpu() for k, v in outs.items()}
+
+
+def cpu_baseline(K, pose, params, sample_rays: int, chunk: int, near: float = 4.0, far: float = 15.0):
+    """The CPU oracle (port of the reference's PyTorch-CPU path) on a bounded sample of the same workload: the first
+    `sample_rays` rays of the image in `chunk`-ray dm_nerf calls (4 chunks of the reference's N_test = 4096 by default,
+    BASELINE.md section 4), after a 256-ray warm-up.  Returns rays/s and the sample's outputs (the checker's side of the
+    deviation statistics)."""
+    from oracle import dmnerf_cpu as oracle
+    torch.set_num_threads(host_cores())
+    c2w = torch.from_numpy(pose)
+    oracle.render_image(H, W, K, c2w, params[0], params[1], near, far, N_SAMPLES, N_IMPORTANCE, chunk=256, max_rays=256)
+    rays_o, rays_d = oracle.rays_from_camera(H, W, K, c2w)
+    rays_o, rays_d = rays_o.reshape(-1, 3).float(), rays_d.reshape(-1, 3).float()
+    outs = {"rgb_fine": [], "depth_fine": [], "ins_fine": []}
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for s in range(0, sample_rays, chunk):
+            n = min(chunk, sample_rays - s)
+            r = oracle.render_rays(torch.stack([rays_o[s:s + n], rays_d[s:s + n]], 0), params[0], params[1],
+                                   oracle.coarse_depths(n, near, far, N_SAMPLES), n_importance=N_IMPORTANCE)
+            for k in outs:
+                outs[k].append(r[k])
+    dt = time.perf_counter() - t0
+    return sample_rays / dt, {k: torch.cat(v, 0) for k, v in outs.items()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,18 +221,22 @@ def main():
                     help="rays per dm_nerf call.  The reference's N_test = 4096 bounds memory on small GPUs; it is a "
                          "tiling parameter (results are partition-invariant bit for bit, tests/test_gpu_parity.py), "
                          "and 65536 saves 2.6 %% of launch ramp and host gaps on the same device (--chunk 4096 for the reference's)")
-    ap.add_argument("--cpu-rays", type=int, default=8192, help="rays of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--precision", default=os.environ.get("DMNERF_PRECISION", "bf16x3"),
+    ap.add_argument("--cpu-rays", type=int, default=4 * CPU_CHUNK,
+                    help="rays of the CPU-baseline sample (0 = skip): 4 chunks of the reference's N_test")
+    ap.add_argument("--precision", default=os.environ.get("DMNERF_PRECISION", "fp32"),
                     choices=["fp32", "fp16x3", "bf16x3"],
-                    help="field-kernel arithmetic: fp32 = exact fp32 MFMA; fp16x3 / bf16x3 = three 16-bit MFMAs "
-                         "per product (hi/lo split, fp32 accumulate)")
+                    help="arithmetic of the headline `value`: fp32 = the reference's (exact fp32 MFMA products; default); "
+                         "fp16x3 / bf16x3 = three 16-bit MFMAs per product (hi/lo split, fp32 accumulate)")
+    ap.add_argument("--split-modes", default="bf16x3,fp16x3",
+                    help="split-precision modes timed over the same --steps after the headline region and reported beside "
+                         "it with their deviation statistics (N = 1 only; '' = none)")
+    ap.add_argument("--no-split-legs", "--no-fp32-leg", dest="no_split", action="store_true",
+                    help="same as --split-modes '' (profiling scripts: only the headline mode runs)")
     ap.add_argument("--workload", default="study", choices=["study", "replica"],
                     help="study = BASELINE config 2 (the headline: DM-SR 'study' 800x800, ins_num 13); replica = config 3 "
                          "shape (room_0: 640x480, ins_num 93, near 0 / far 6.5) for a side measurement")
     ap.add_argument("--no-train-leg", action="store_true",
                     help="skip the extra training-step measurement after the timed region (N = 1 only)")
-    ap.add_argument("--no-fp32-leg", action="store_true",
-                    help="skip the extra 2 images rendered in exact-fp32 mode after the timed region (N = 1 only)")
     ns = ap.parse_args()
 
     global H, W, INS_NUM, MACS_PER_POINT, FLOP_PER_POINT
@@ -186,28 +270,21 @@ def main():
     dm.load_library()
     nerf, K, poses, params = synthetic_scene(device, near, far)
     pos, view, coarse, fine, args = nerf
-    args.precision = ns.precision
     pose = poses[rank % len(poses)]
     hwk = [H, W, K]
 
-    def step():
-        return dm.render_image(pos, view, coarse, fine, pose, hwk, args, chunk=ns.chunk)
+    def make_step(precision, **kw):
+        from types import SimpleNamespace
+        a = SimpleNamespace(**{**vars(args), "precision": precision})
+        return lambda: dm.render_image(pos, view, coarse, fine, pose, hwk, a, chunk=ns.chunk, **kw)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(ns.warmup):
-        step()
-    barrier()
-    ops.PROFILE = []
-    t0 = time.perf_counter()
-    for _ in range(ns.steps):
-        rgb, ins = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    profile, ops.PROFILE = ops.PROFILE, None
+    # ---- the timed region: --warmup untimed images, then exactly --steps images
+    elapsed, profile, (rgb, ins) = timed_images(make_step(ns.precision), ns.steps, ns.warmup, barrier)
     if dist is not None:
         from dm_nerf_amd.parallel import max_over_ranks
         elapsed = max_over_ranks(elapsed, device)
@@ -220,112 +297,88 @@ def main():
 
     rays_total = world * ns.steps * H * W
     value = rays_total / elapsed
-
-    # per-kernel durations from HIP events recorded on the launch stream inside the timed region
-    def kernel_stats(name):
-        rows = [(a.elapsed_time(b) * 1e-3, work) for k, a, b, work in profile if k == name]
-        secs = float(sum(r[0] for r in rows))
-        return len(rows), secs, int(sum(r[1] for r in rows))
-
-    n_f, t_f, pts_f = kernel_stats("field_fwd")
-    n_c, t_c, pts_c = kernel_stats("composite")
-    field_tflops = pts_f * FLOP_PER_POINT / t_f / 1e12
-    x3 = ns.precision != "fp32"
-    peak = PEAK_16BIT_MFMA_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS
-    kernel_name = (f"field_fwd_x3_kernel<{ns.precision}> (fused encodings + 8x256 field; every fp32 product = 3 "
-                   "16-bit MFMA products on hi/lo splits, fp32 accumulate)" if x3 else
-                   "field_fwd_kernel<1> (fused encodings + 8x256 field, fp32 MFMA)")
+    n_c, t_c, pts_c = kernel_stats(profile, "composite")
     c_ch = 5 + INS_NUM
     # composite launches alternate S=64 and S=192 with the same ray count; bytes by sample total
     comp_bytes = (pts_c // (N_SAMPLES + N_SAMPLES + N_IMPORTANCE)) * (
         composite_bytes(1, N_SAMPLES, c_ch) + composite_bytes(1, N_SAMPLES + N_IMPORTANCE, c_ch))
     comp_gbs = comp_bytes / t_c / 1e9
+    dtype_names = {"fp32": "f32", "fp16x3": "f16x3 (hi/lo split, f32 accumulate)",
+                   "bf16x3": "bf16x3 (hi/lo split, f32 accumulate)"}
 
     out = {
         "metric": f"rays/sec, {'DM-SR study 800x800' if ns.workload == 'study' else scene}, 64+128 samples (PSNR vs "
                   "reference path in `psnr_vs_cpu_oracle_db`)",
         "value": value, "unit": "rays/s", "n_gpus": world, "steps": ns.steps, "warmup": ns.warmup,
         "ms_per_step": elapsed / ns.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": {"fp32": "f32", "fp16x3": "f16x3 (hi/lo split, f32 accumulate)",
-                                       "bf16x3": "bf16x3 (hi/lo split, f32 accumulate)"}[ns.precision],
-        "data": "synthetic",
+        "vs_baseline": None, "dtype": dtype_names[ns.precision], "data": "synthetic",
         "config": {"workload": f"{scene}, 64+128 hierarchical, 8x256 field, RGB+sigma+instance head "
                                f"(ins_num={INS_NUM}), 1 image per GPU per step", "chunk_rays": ns.chunk,
                    "precision": ns.precision, "parallelism": f"ray/image-sharded x{world}, no collective"},
-        "roofline": {"kernel": kernel_name, "bound": "mfma",
-                     "achieved": field_tflops, "peak": peak, "unit": "TFLOP/s",
-                     "frac": field_tflops / peak, "traffic": None,
-                     "mfma_flop_issued_per_algorithmic_flop": 3 if x3 else 1,
-                     "launches": n_f, "avg_launch_ms": t_f / max(n_f, 1) * 1e3,
-                     "algorithmic_flop_per_launch": pts_f * FLOP_PER_POINT / max(n_f, 1),
-                     "time_share_of_step": t_f / elapsed,
-                     # nominal peak is at 2.4 GHz; the device sustains less with every CU on 16-bit MFMA (board power
-                     # limit): tools/mfma_peak.hip, profiles/r01d_mfma_sustained_peak.txt
-                     "peak_sustained_measured": SUSTAINED_MFMA_TFLOPS[ns.precision],
-                     "mfma_issue_frac_of_sustained": (3 if x3 else 1) * field_tflops
-                                                     / SUSTAINED_MFMA_TFLOPS[ns.precision]},
-        "roofline_composite": {"kernel": "composite_kernel (LDS-staged slabs + wave product scan)", "bound": "hbm",
-                               "achieved": comp_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+        "roofline": field_roofline(profile, ns.precision, elapsed),
+        "roofline_composite": {"kernel": ("composite_wide_kernel (rows straight from global memory, lane per channel)"
+                                          if c_ch > 32 else "composite_kernel (LDS-staged slabs + wave product scan)"),
+                               "bound": "hbm", "achieved": comp_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                "frac": comp_gbs / PEAK_HBM_GBS, "traffic": None, "launches": n_c,
-                               "avg_launch_ms": t_c / max(n_c, 1) * 1e3, "time_share_of_step": t_c / elapsed},
+                               "avg_launch_ms": t_c / max(n_c, 1) * 1e3, "time_share_of_step": t_c / elapsed,
+                               "algorithmic_bytes_per_launch": comp_bytes / max(n_c, 1)},
     }
 
     traffic_file = os.path.join(ROOT, "profiles", "composite_traffic.json")
-    if os.path.exists(traffic_file):        # HBM bytes per composite launch from rocprofv3 PMC passes (tools/pmc_l2.sh)
-        meas = json.load(open(traffic_file))
-        out["roofline_composite"]["traffic"] = meas["hbm_bytes_per_ray"] * (pts_c // 256) / max(n_c, 1)   # per launch
-        out["roofline_composite"]["traffic_source"] = meas["source"]
-        out["roofline_composite"]["algorithmic_bytes_per_launch"] = comp_bytes / max(n_c, 1)
+    if os.path.exists(traffic_file):        # HBM bytes per composite launch from rocprofv3 PMC passes (tools/pmc_composite.sh)
+        meas = json.load(open(traffic_file)).get(f"{ns.workload}_chunk{ns.chunk}")
+        if meas is not None:                # measured at exactly this launch size (rays per launch, S mix, C)
+            out["roofline_composite"]["traffic"] = meas["hbm_bytes_per_launch"]
+            out["roofline_composite"]["traffic_source"] = meas["source"]
 
-    if x3 and world == 1 and not ns.no_fp32_leg:
-        # the same image once more with exact fp32 MFMA products, for reference beside the headline mode
-        args.precision = "fp32"
-        step()
-        torch.cuda.synchronize()
-        ops.PROFILE = []
-        t1 = time.perf_counter()
-        rgb32, _ = step()
-        torch.cuda.synchronize()
-        dt32 = time.perf_counter() - t1
-        prof32, ops.PROFILE = ops.PROFILE, None
-        rows = [(a.elapsed_time(b) * 1e-3, w) for k, a, b, w in prof32 if k == "field_fwd"]
-        tf32 = sum(w for _, w in rows) * FLOP_PER_POINT / sum(t for t, _ in rows) / 1e12
-        out["fp32_exact_mode"] = {"value": H * W / dt32, "unit": "rays/s", "ms_per_step": dt32 * 1e3,
-                                  "roofline": {"kernel": "field_fwd_kernel<1> (fp32 MFMA)", "bound": "mfma",
-                                               "achieved": tf32, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                               "frac": tf32 / PEAK_F32_MFMA_TFLOPS},
-                                  "max_abs_rgb_diff_vs_headline_mode": float((rgb32 - rgb).abs().max())}
-        args.precision = ns.precision
-
-    if x3 and world == 1 and not ns.no_fp32_leg:
-        # the same image loop with the coarse pass reduced to density (render_image(image_only=True)): identical images,
-        # the coarse network's colour / instance heads are not evaluated.  Reported beside `value`, never as it.
-        only = lambda: dm.render_image(pos, view, coarse, fine, pose, hwk, args, chunk=ns.chunk, image_only=True)
+    # ---- beside the headline (N = 1 only, outside its timed region): the split-precision modes over the same --steps
+    modes = [m for m in ns.split_modes.split(",") if m and m != ns.precision] if world == 1 and not ns.no_split else []
+    images = {ns.precision: rgb}
+    if modes:
+        out["split_precision_modes"] = {}
+    for mode in modes:
+        e_m, prof_m, (rgb_m, _) = timed_images(make_step(mode), ns.steps, min(ns.warmup, 2) or 1, barrier)
+        images[mode] = rgb_m
+        entry = {"value": ns.steps * H * W / e_m, "unit": "rays/s", "steps": ns.steps, "ms_per_step": e_m / ns.steps * 1e3,
+                 "dtype": dtype_names[mode], "roofline": field_roofline(prof_m, mode, e_m)}
+        if ns.precision == "fp32":          # whole image against the exact-arithmetic render of the same pose
+            entry["whole_image_vs_fp32_mode"] = deviation_stats(rgb_m.reshape(-1, 3), rgb.reshape(-1, 3))
+        # the same image loop with the coarse pass reduced to density (render_image(image_only=True)): bit-identical images,
+        # the coarse network's colour / instance heads are not evaluated.  Reported beside, never as `value`.
+        only = make_step(mode, image_only=True)
         rgb_only, _ = only()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         only()
         torch.cuda.synchronize()
         dt_only = time.perf_counter() - t1
-        out["image_only_mode"] = {"value": H * W / dt_only, "unit": "rays/s", "ms_per_step": dt_only * 1e3,
-                                  "identical_to_headline_image": bool(torch.equal(rgb_only, rgb)),
-                                  "note": "coarse pass evaluates sigma only; outputs of render_test are unchanged"}
+        entry["image_only_coarse_pass"] = {"value": H * W / dt_only, "unit": "rays/s", "ms_per_step": dt_only * 1e3,
+                                           "identical_image": bool(torch.equal(rgb_only, rgb_m))}
+        out["split_precision_modes"][mode] = entry
 
     if world == 1 and not ns.no_train_leg:
         out["training_step"] = training_leg(nerf, K, poses[0], device)
 
     if ns.cpu_rays > 0 and world == 1:       # the CPU baseline is timed on rank 0 at N = 1 only
-        cpu_rps, cpu_rgb, cpu_ins = cpu_baseline(K, pose, params, ns.cpu_rays, CPU_CHUNK, near, far)
+        cpu_rps, cpu_out = cpu_baseline(K, pose, params, ns.cpu_rays, CPU_CHUNK, near, far)
         got = rgb.reshape(-1, 3)[: ns.cpu_rays].cpu()
-        mse = float(torch.mean((got - cpu_rgb) ** 2))
+        mse = float(torch.mean((got - cpu_out["rgb_fine"]) ** 2))
         out["psnr_vs_cpu_oracle_db"] = float(-10.0 * np.log10(max(mse, 1e-20)))
-        out["max_abs_err_rgb_vs_cpu_oracle"] = float((got - cpu_rgb).abs().max())
+        out["max_abs_err_rgb_vs_cpu_oracle"] = float((got - cpu_out["rgb_fine"]).abs().max())
         out["cpu_baseline"] = {
             "value": cpu_rps, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"first {ns.cpu_rays} rays of the same 800x800 image in {CPU_CHUNK}-ray chunks through "
-                      "oracle/dmnerf_cpu.py (PyTorch CPU fp32, same op sequence as the reference), after a "
-                      "256-ray warm-up"}
+            "sample": f"first {ns.cpu_rays} rays of the same image in {CPU_CHUNK}-ray chunks "
+                      f"({ns.cpu_rays // CPU_CHUNK} chunks) through oracle/dmnerf_cpu.py (PyTorch CPU fp32, same op "
+                      "sequence as the reference), after a 256-ray warm-up"}
         out["gpu_over_cpu"] = value / cpu_rps
+        # deviation of every mode from the CPU oracle on the sample rays, the same chunking on both sides
+        # (relative = per-ray worst element over max|oracle|; the oracle itself moves by 2e-4 against an fp64 run of the
+        # reference behind the sampler)
+        dev = {}
+        for mode in [ns.precision] + modes:
+            gpu_out = sample_outputs(nerf, K, pose, mode, ns.cpu_rays, CPU_CHUNK)
+            dev[mode] = {k: deviation_stats(gpu_out[k], cpu_out[k]) for k in ("rgb_fine", "depth_fine", "ins_fine")}
+        out["deviation_vs_cpu_oracle"] = dev
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

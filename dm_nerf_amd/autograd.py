@@ -8,54 +8,19 @@ Forward of both functions is the hand-written HIP kernel.  Backward:
   backward-data kernel chains dL/d pre-activation through the layers in registers, a split-K MFMA kernel reduces
   the 30 weight/bias gradients over all sample points.  ``args.precision`` selects the forward under autograd:
   exact fp32, or three bf16 MFMAs per product for "bf16x3" / "fp16x3".
-  ``FieldFnLibrary`` (library GEMMs on recomputed activations, ``torch_field_on_rays``) is the cross-check.
-  Nothing here runs on the CPU.
+  Nothing here runs on the CPU; the library-GEMM cross-check of these kernels lives with the tests
+  (``tests/library_backward.py``).
 
 Only parameters receive gradients: rays and depths never need them (``z_samples.detach()``,
 networks/render.py:68)."""
 from __future__ import annotations
 
-from typing import Dict, List
+from typing import List
 
 import torch
-import torch.nn.functional as F
 
 from . import ops
 from ._lib import check, current_stream, load, ptr
-
-POS_FREQS, DIR_FREQS, POS_CH = 10, 4, 63
-
-
-def _encode(x: torch.Tensor, n_freqs: int) -> torch.Tensor:
-    """networks/dm_nerf.py:17-38 with torch ops on the device (backward recompute only)."""
-    parts = [x]
-    for k in range(n_freqs):
-        parts.append(torch.sin(x * float(2 ** k)))
-        parts.append(torch.cos(x * float(2 ** k)))
-    return torch.cat(parts, -1)
-
-
-def torch_field_on_rays(p: Dict[str, torch.Tensor], rays_o, rays_d, z) -> torch.Tensor:
-    """The field network on ``o + d*z`` with differentiable torch ops (networks/render.py:37-38,49-61,
-    networks/dm_nerf.py:80-106): used to rebuild the activations for the parameter gradients."""
-    view = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
-    pts = rays_o[:, None, :] + rays_d[:, None, :] * z[:, :, None]
-    pos = _encode(pts.reshape(-1, 3), POS_FREQS)
-    vdir = _encode(view[:, None, :].expand(pts.shape).reshape(-1, 3), DIR_FREQS)
-    h = pos
-    for i in range(8):
-        h = F.relu(F.linear(h, p[f"mlps.{i}.weight"], p[f"mlps.{i}.bias"]))
-        if i == 4:
-            h = torch.cat([h, pos], -1)
-    feat = F.linear(h, p["rgb_feature_linear.weight"], p["rgb_feature_linear.bias"])
-    feat = F.relu(F.linear(torch.cat([feat, vdir], -1), p["rgb_feature_linears.0.weight"],
-                           p["rgb_feature_linears.0.bias"]))
-    code = F.linear(h.detach(), p["ins_feature_linear.weight"], p["ins_feature_linear.bias"])   # dm_nerf.py:95
-    code = F.relu(F.linear(code, p["ins_feature_linears.0.weight"], p["ins_feature_linears.0.bias"]))
-    sigma = F.linear(h, p["density_linear.weight"], p["density_linear.bias"])
-    rgb = F.linear(feat, p["rgb_linear.weight"], p["rgb_linear.bias"])
-    ins = F.linear(code, p["ins_linear.weight"], p["ins_linear.bias"])
-    return torch.cat([rgb, sigma, ins], -1).reshape(z.shape[0], z.shape[1], -1)
 
 
 class FieldFn(torch.autograd.Function):
@@ -74,11 +39,16 @@ class FieldFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_raw):
+        if ctx.save is None:
+            raise RuntimeError("dm_nerf_amd: the field's save record is released by its first backward pass (it is "
+                               "11.7 KB per sample point); a second backward through the same forward "
+                               "(retain_graph=True) is not supported -- run the forward again")
         model = ctx.model
         n_params = sum(n for _, n, _ in ctx.meta)
         blob = model.blob("bwd" if DATA_PRECISION == "fp32" else "bwd_x3")
         flat = ops.field_backward(g_raw, ctx.save, blob, model.ins_num, model.wgrad_index(), n_params,
-                                  wgrad_precision=WGRAD_PRECISION, data_precision=DATA_PRECISION)
+                                  wgrad_precision=WGRAD_PRECISION, data_precision=DATA_PRECISION,
+                                  out=model.grad_buffer())      # a GradBucket's slice when one was adopted
         ctx.save = None
         out: List = []
         at = 0
@@ -88,39 +58,8 @@ class FieldFn(torch.autograd.Function):
         return (None, None, None, None, None, *out)
 
 
-class FieldFnLibrary(torch.autograd.Function):
-    """Same function with the round-1 backward: parameter gradients through library GEMMs (rocBLAS via torch) on
-    activations recomputed from the saved rays and depths.  Kept as the on-device cross-check of ``FieldFn``
-    (tests) and for A/B timing (``FIELD_BACKWARD = "library"``)."""
-
-    @staticmethod
-    def forward(ctx, rays_o, rays_d, z, model, precision, *params):
-        raw = ops.field_rays(rays_o, rays_d, z, model.blob(precision), model.ins_num, precision)
-        ctx.save_for_backward(rays_o, rays_d, z.contiguous())
-        ctx.names = [n for n, _ in model.named_parameters()]
-        ctx.params = params
-        return raw
-
-    @staticmethod
-    def backward(ctx, g_raw):
-        rays_o, rays_d, z = ctx.saved_tensors
-        leaves = [p.detach().requires_grad_(p.requires_grad) for p in ctx.params]
-        with torch.enable_grad():
-            raw = torch_field_on_rays(dict(zip(ctx.names, leaves)), rays_o, rays_d, z)
-        wanted = [t for t in leaves if t.requires_grad]
-        grads = torch.autograd.grad(raw, wanted, g_raw.contiguous(), allow_unused=True)
-        it = iter(grads)
-        out: List = [next(it) if t.requires_grad else None for t in leaves]
-        return (None, None, None, None, None, *out)
-
-
-FIELD_BACKWARD = "hip"          # "library": FieldFnLibrary
 DATA_PRECISION = "bf16x3"       # backward-data chain: "bf16x3" or "fp32" (exact MFMA); masks come from the save record
 WGRAD_PRECISION = "bf16x3"      # weight-gradient GEMMs: "bf16x3" (three bf16 MFMAs per product) or "fp32" (exact MFMA)
-
-
-def field_fn():
-    return FieldFn if FIELD_BACKWARD == "hip" else FieldFnLibrary
 
 
 class CompositeFn(torch.autograd.Function):

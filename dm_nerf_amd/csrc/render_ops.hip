@@ -379,7 +379,8 @@ __device__ __forceinline__ float linspace01(int k, int n) {
   return k < n / 2 ? __fmul_rn(step, (float)k) : fmaf(-step, (float)(n - 1 - k), 1.f);
 }
 
-// ascending rank sort of L values held in LDS `vals` into global `out` (ties by index)
+// ascending rank sort of L values held in LDS `vals` into global `out` (ties by index).  NaNs order after every
+// number (as torch.sort does), again by index, so the ranks stay a permutation and every output slot is written.
 __device__ void rank_sort_to(const float* vals, int L, float* __restrict__ out, int lane) {
   for (int e0 = 0; e0 < L; e0 += 256) {   // four candidates per lane per pass
     float v[4];
@@ -393,7 +394,11 @@ __device__ void rank_sort_to(const float* vals, int L, float* __restrict__ out, 
     for (int f = 0; f < L; ++f) {
       const float x = vals[f];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) rank[q] += (x < v[q] || (x == v[q] && f < id[q])) ? 1 : 0;
+      for (int q = 0; q < 4; ++q) {
+        const bool xn = x != x, vn = v[q] != v[q];
+        const bool before = x < v[q] || (vn && !xn), same = x == v[q] || (xn && vn);
+        rank[q] += (before || (same && f < id[q])) ? 1 : 0;
+      }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q)

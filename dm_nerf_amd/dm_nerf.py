@@ -78,6 +78,7 @@ class DM_NeRF(nn.Module):
         self.precision = "fp32"          # arithmetic of forward(); the render path passes its own
         self._blobs = {}                 # precision -> (key, blob)
         self._indices = {}               # (flavour, device) -> gather table
+        self._grad_flat = None           # persistent flat gradient buffer (parallel.GradBucket hands out slices)
 
     # ---- packed weights -------------------------------------------------------------------
     def _ordered_params(self) -> List[torch.Tensor]:
@@ -86,7 +87,9 @@ class DM_NeRF(nn.Module):
     def blob(self, precision: str = "fp32") -> torch.Tensor:
         """Device blob consumed by the field kernel of the given precision ("bwd" / "bwd_x3": the transposed-weight
         blobs of the exact and the bf16x3 backward-data kernel); re-gathered only when a parameter changed
-        (optimizer steps and load_state_dict bump the tensors' version counters)."""
+        (optimizer steps, ``load_state_dict`` and every other in-place op bump the tensors' version counters).
+        Writes THROUGH ``p.data`` (``p.data.mul_(..)``, legacy init / EMA / clipping code) bypass the version counter by
+        design of autograd: call ``invalidate_blobs()`` after such a write."""
         if precision not in ("bwd", "bwd_x3"):
             ops.precision_code(precision)
         params = self._ordered_params()
@@ -111,6 +114,28 @@ class DM_NeRF(nn.Module):
             blob = ops.pack_blob(flat, index)
         self._blobs[precision] = (key, blob)
         return blob
+
+    def adopt_grad_buffer(self, flat: torch.Tensor) -> None:
+        """Use ``flat`` (fp32, one float per parameter, state_dict order) as the destination of the weight-gradient
+        kernel: after ``backward()`` every ``p.grad`` is a view of it (``parallel.GradBucket``)."""
+        n = sum(p.numel() for p in self.parameters())
+        if flat.dtype != torch.float32 or flat.numel() != n or not flat.is_contiguous():
+            raise ValueError(f"gradient buffer must be {n} contiguous float32")
+        self._grad_flat = flat
+
+    def grad_buffer(self):
+        """The adopted flat gradient buffer if the kernel may write it now (no parameter holds a gradient yet that
+        lives in it or would have to be accumulated into), else None."""
+        flat = self._grad_flat
+        if flat is None or flat.device != self._ordered_params()[0].device:
+            return None
+        if any(p.grad is not None for p in self.parameters()):
+            return None
+        return flat
+
+    def invalidate_blobs(self) -> None:
+        """Drop the packed-weight cache (needed only after parameter writes through ``.data``, see ``blob``)."""
+        self._blobs.clear()
 
     def wgrad_index(self) -> torch.Tensor:
         """Scatter table of the weight-gradient kernel (ops.field_backward) on the parameters' device."""

@@ -43,22 +43,42 @@ class _ClassStatsFn(torch.autograd.Function):
         return g_pred, None, None
 
 
-def ins_criterion(pred_ins: torch.Tensor, gt_labels: torch.Tensor, ins_num: int):
+def ins_criterion(pred_ins: torch.Tensor, gt_labels: torch.Tensor, ins_num: int, reduce=None):
     """``(ins_loss_sum, valid_ce, invalid_ce, valid_siou)`` of networks/evaluator.py:19-38 for ``pred_ins [N, ins_num]``
     (the rendered, sigmoided instance map) and integer ``gt_labels [N]``.  All four are 0-dim tensors
-    (the reference's ``invalid_ce`` is ``tensor([0])`` when every column is matched)."""
+    (the reference's ``invalid_ce`` is ``tensor([0])`` when every column is matched).
+
+    ``reduce`` (ray-sharded training, ``parallel.ShardReducer``): called as ``reduce(tag, tensor)`` on the label-presence
+    mask, the class counts, the ray count and the ``[3, V, K]`` class statistics; it returns their sums over all shards.
+    Matching and normalisation then see the whole batch (evaluator.py:21,60-70), every rank computes the same loss
+    value, and its backward reaches the rank's own rays only -- so gradients must be SUMMED over ranks."""
     from scipy.optimize import linear_sum_assignment
 
     if pred_ins.dim() != 2 or pred_ins.shape[1] != ins_num or gt_labels.shape[0] != pred_ins.shape[0]:
         raise ValueError("pred_ins must be [N, ins_num] and gt_labels [N]")
     n = pred_ins.shape[0]
-    valid, classes = torch.unique(gt_labels.long(), return_inverse=True)              # :21, :25 (sorted labels)
-    v = int(valid.numel())                                                            # :24
+    labels = gt_labels.long()
+    if reduce is None:
+        valid, classes = torch.unique(labels, return_inverse=True)                    # :21, :25 (sorted labels)
+        v = int(valid.numel())                                                        # :24
+        count = torch.bincount(classes, minlength=v).to(torch.float32)[:, None]
+    else:
+        # labels present in ANY shard, in sorted order (torch.unique over the whole batch)
+        if n and (int(labels.min()) < 0 or int(labels.max()) > ins_num):
+            raise ValueError("sharded ins_criterion needs labels in [0, ins_num]")
+        per_label = reduce("ins_label_count", torch.bincount(labels, minlength=ins_num + 1).to(torch.float32))
+        present = per_label > 0
+        v = int(present.sum())
+        slot = torch.cumsum(present.long(), 0) - 1                                    # label -> row of the class axis
+        classes = slot[labels]
+        count = per_label[present][:, None]
+        n = int(round(float(reduce("ins_ray_count", torch.tensor([float(n)], device=pred_ins.device)))))
     if v > ins_num:
         raise ValueError(f"{v} distinct labels but only {ins_num} instance columns")
     stats = _ClassStatsFn.apply(pred_ins, classes.contiguous(), v)
+    if reduce is not None:
+        stats = reduce("ins_class_stats", stats)
     s1, s0, tp = stats[0], stats[1], stats[2]
-    count = torch.bincount(classes, minlength=v).to(torch.float32)[:, None]
     cost_ce = -(s1 + (s0.sum(0, keepdim=True) - s0)) / n                              # :60
     fp = tp.sum(0, keepdim=True) - tp                                                 # :63-65
     fn = count - tp

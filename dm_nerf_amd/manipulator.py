@@ -2,8 +2,9 @@
 ``dm_nerf`` (``manipulator_nerf`` / ``manipulator_render``), the label surgery between the original and the
 transformed scene (``exchanger``) and the two-pass re-render that strings them together (``manipulator``).  The demo /
 evaluation drivers around them (image and json writers, metrics) are out of scope.
-The reference module does not import in the build image (imageio / cv2 / lpips): these are restated from its text and
-checked against a second, independent restatement on the test side -- "parity unpinned"."""
+Pinned by G12 (``tests/golden/make_golden.py:g12_manipulator``): the reference's own four function definitions,
+compiled from its source text, run on the seeded cases; ``exchanger`` is held to bit equality, the re-render to the
+path tolerances."""
 from __future__ import annotations
 
 import torch
@@ -75,16 +76,20 @@ def manipulator(position_embedder, view_embedder, model_coarse, model_fine, ori_
     """Two-pass re-render of a scene with moved objects (networks/manipulator.py:136-205): coarse fields of the
     original rays and of every object's inversely transformed rays, their composited labels at 64 + 128 depths, the
     exchange, then the same at the union of all resampled depths with the fine field.  ``args``: ``N_samples``,
-    ``N_importance``, ``near``, ``far``, ``target_label`` (one label per entry of ``f_tar_rays``).
+    ``N_importance``, ``near``, ``far``, ``target_label`` (one label per entry of ``f_tar_rays``); optional
+    ``args.u_draws``: the uniform draws of the ``2 + len(f_tar_rays)`` ``sample_pdf`` calls in call order (the reference
+    draws them with the global ``torch.rand``, helpers.py:135), so that a run can be checked against recorded draws.
     Returns ``(final_rgb, final_ins, tar_rgb, tar_ins_accum)``."""
     n_samples, n_importance, near, far = args.N_samples, args.N_importance, args.near, args.far
+    draws = list(getattr(args, "u_draws", None) or [])
 
     def resampled(z, weights):
         mid = 0.5 * (z[..., 1:] + z[..., :-1])
-        return sample_pdf(mid, weights[..., 1:-1], n_importance)                               # det=False, :146,168
+        u = draws.pop(0) if draws else None
+        return sample_pdf(mid, weights[..., 1:-1], n_importance, u=u)                          # det=False, :146,168
 
     def labels_at(rays, z, z_new):
-        z_full, _ = torch.sort(torch.cat([z, z_new], -1), -1)
+        z_full = ops.merge_depths(z, z_new)                                                    # sort(cat), :148
         raw_full, _ = manipulator_nerf(rays, position_embedder, view_embedder, model_fine, z_vals=z_full)
         return manipulator_render(raw_full, z_full, rays[1])[3]
 
@@ -107,11 +112,11 @@ def manipulator(position_embedder, view_embedder, model_coarse, model_fine, ori_
         # step 2 (:181-203): weights of the exchanged scene, all resampled depths merged, fine fields, exchange again
         _, ori_w, _, _ = manipulator_render(ori_raw, ori_z, ori_rays[1])
         ori_new = resampled(ori_z, ori_w)
-        extra = torch.cat(tar_samples, -1)
-        ori_z_all, _ = torch.sort(torch.cat([ori_z, ori_new, extra], -1), -1)
+        extra = torch.cat([ori_new] + tar_samples, -1)                                         # :190-191
+        ori_z_all = ops.merge_depths(ori_z, extra)
         ori_raw, _ = manipulator_nerf(ori_rays, position_embedder, view_embedder, model_fine, z_vals=ori_z_all)
         for idx, tar_rays in enumerate(f_tar_rays):
-            tar_z_all, _ = torch.sort(torch.cat([tar_zs[idx], ori_new, extra], -1), -1)
+            tar_z_all = ops.merge_depths(tar_zs[idx], extra)                                   # :197
             tar_raws[idx], _ = manipulator_nerf(tar_rays, position_embedder, view_embedder, model_fine, z_vals=tar_z_all)
         ori_raw, _, _, _ = exchanger(ori_raw.contiguous(), tar_raws, ori_ins_accum, tar_ins_accums, args.target_label)
         final_rgb, _, _, final_ins = manipulator_render(ori_raw, ori_z_all, ori_rays[1])

@@ -282,10 +282,12 @@ def field_rays_save(rays_o: torch.Tensor, rays_d: torch.Tensor, z: torch.Tensor,
 
 def field_backward(g_raw: torch.Tensor, save: torch.Tensor, bwd_blob: torch.Tensor, ins_num: int,
                    wgrad_idx: torch.Tensor, n_params: int, splits: Optional[int] = None,
-                   wgrad_precision: str = "bf16x3", data_precision: str = "fp32") -> torch.Tensor:
+                   wgrad_precision: str = "bf16x3", data_precision: str = "fp32",
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dL/d raw [N,S,C] + save record -> flat parameter gradient (state_dict order).  ``data_precision`` /
     ``wgrad_precision``: arithmetic of the backward-data chain and of the weight-gradient GEMMs, "fp32" (exact
-    MFMA) or "bf16x3" (three bf16 MFMAs per product); ``bwd_blob`` must be the blob of ``data_precision``."""
+    MFMA) or "bf16x3" (three bf16 MFMAs per product); ``bwd_blob`` must be the blob of ``data_precision``.
+    ``out``: flat fp32 destination (the scatter table covers every parameter exactly once, so it is overwritten)."""
     for prec in (wgrad_precision, data_precision):
         if prec not in ("fp32", "bf16x3"):
             raise ValueError("backward precisions are 'fp32' or 'bf16x3' (gradients underflow fp16)")
@@ -310,7 +312,14 @@ def field_backward(g_raw: torch.Tensor, save: torch.Tensor, bwd_blob: torch.Tens
             check(lib.dmn_field_bwd_data_x3(ptr(g_raw), ptr(save), ptr(bwd_blob), m, ins_num, ptr(grec),
                                             current_stream()), "dmn_field_bwd_data_x3")
     work = torch.empty(lib.dmn_field_wgrad_workspace_floats(ins_num, splits), dtype=torch.float32, device=dev)
-    grads = torch.zeros(n_params, dtype=torch.float32, device=dev)
+    if out is None:
+        grads = torch.empty(n_params, dtype=torch.float32, device=dev)
+    else:
+        if out.dtype != torch.float32 or out.numel() != n_params or not out.is_contiguous() or out.device != dev:
+            raise ValueError("out must be a contiguous float32 tensor with one entry per parameter on the same device")
+        grads = out
+    if m == 0:
+        return grads.zero_()
     with _timed("field_bwd_weights", m):
         check(lib.dmn_field_bwd_weights(ptr(save), ptr(grec), m, ins_num, ptr(wgrad_idx), splits,
                                         precision_code(wgrad_precision), ptr(work), ptr(grads), 0,

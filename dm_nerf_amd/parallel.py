@@ -46,22 +46,92 @@ def max_over_ranks(value: float, device, group=None) -> float:
     return float(t.item())
 
 
+class GradBucket:
+    """One persistent flat fp32 buffer holding every gradient of the given modules (2 x 696,338 floats = 5.57 MB for
+    the coarse + fine pair).  ``DM_NeRF`` modules adopt their slice as the destination of the
+    weight-gradient kernel, so after ``backward()`` the parameters' ``.grad`` already ARE views of this buffer and the
+    data-parallel step is ONE in-place all-reduce over it (RCCL over xGMI: a ring is per-link bound, one large message
+    is the cheap shape) -- no concatenation, no copy back.  Gradients that arrived some other way (another module
+    type, a second backward into existing grads) are copied in once and re-pointed."""
+
+    def __init__(self, models):
+        self.params = [p for m in models for p in m.parameters()]
+        if not self.params:
+            raise ValueError("no parameters")
+        dev = self.params[0].device
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
+        self.views, offset = [], 0
+        for p in self.params:
+            self.views.append(self.flat[offset:offset + p.numel()].view_as(p))
+            offset += p.numel()
+        offset = 0
+        for m in models:
+            n = sum(p.numel() for p in m.parameters())
+            if hasattr(m, "adopt_grad_buffer"):
+                m.adopt_grad_buffer(self.flat[offset:offset + n])
+            offset += n
+
+    def _collect(self) -> None:
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
+            p.grad = v
+
+    def allreduce(self, group=None, scale: float = 1.0) -> int:
+        """SUM over ranks, then ``* scale`` (1/world for replicated-mean losses; 1.0 when every rank's loss terms are
+        already weighted by its share of the batch, ``trainer.train_step(shard=...)``).  Returns the float count."""
+        import torch.distributed as dist
+        self._collect()
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        if scale != 1.0:
+            self.flat.mul_(scale)
+        return self.flat.numel()
+
+
+class _AllReduceSum(torch.autograd.Function):
+    """y = sum over ranks of x.  Every rank then evaluates the same (replicated) loss on y, and its backward reaches
+    only its own x: d loss / d x_r = d loss / d y, the identity -- the per-rank parameter gradients are partial sums
+    that the gradient all-reduce (SUM) completes."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        import torch.distributed as dist
+        y = x.detach().clone()
+        dist.all_reduce(y, op=dist.ReduceOp.SUM, group=group)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class ShardReducer:
+    """``reduce(tag, tensor)`` hook of the loss heads for ray-sharded training (``ins_criterion(..., reduce=)``,
+    ``ins_penalizer(..., reduce=)``): sums the batch statistics the losses match and normalise on -- the ``[3, V, K]``
+    class statistics, class / ray counts, the penalizer's four sums -- over all ranks, so that an N-rank step optimises
+    the loss of the whole batch (networks/evaluator.py:21,60-70, networks/penalizer.py:42-43,52).
+    A few hundred bytes per call."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def __call__(self, tag: str, t: torch.Tensor) -> torch.Tensor:
+        return _AllReduceSum.apply(t, self.group)
+
+
+_buckets = {}
+
+
 def allreduce_gradients(models, group=None, average: bool = True) -> int:
-    """Data-parallel training step, communication part: ONE all-reduce over a single flat fp32 buffer holding
-    every gradient of the given modules (2 x 696,338 floats = 5.57 MB for the coarse + fine pair; SURVEY.md
-    section 8e), instead of 60 small ones.  Over xGMI a ring all-reduce is per-link bound, so one large message
-    is the cheap shape.  Returns the number of floats reduced."""
+    """Data-parallel training step, communication part: ONE all-reduce over the persistent flat buffer of a
+    ``GradBucket`` (made on first use for this set of modules).  ``average=False`` leaves the sum (shard-weighted
+    losses).  Returns the number of floats reduced."""
     import torch.distributed as dist
-    params = [p for m in models for p in m.parameters() if p.grad is not None]
-    if not params:
-        return 0
-    flat = torch.cat([p.grad.reshape(-1) for p in params])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    if average:
-        flat /= dist.get_world_size(group)
-    offset = 0
-    for p in params:
-        n = p.numel()
-        p.grad.copy_(flat[offset:offset + n].view_as(p.grad))
-        offset += n
-    return offset
+    models = list(models)
+    key = tuple(id(m) for m in models)
+    bucket = _buckets.get(key)
+    if bucket is None or any(a is not b for a, b in zip(bucket.params, [p for m in models for p in m.parameters()])):
+        bucket = _buckets[key] = GradBucket(models)
+    return bucket.allreduce(group, 1.0 / dist.get_world_size(group) if average else 1.0)

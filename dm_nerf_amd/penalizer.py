@@ -11,7 +11,7 @@ from ._lib import check, current_stream, load, ptr
 
 class _PenalizerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, raw, z, depth, rays_d, tolerance, deta_w):
+    def forward(ctx, raw, z, depth, rays_d, tolerance, deta_w, reduce):
         n, s, c = raw.shape
         raw = ops._dev(raw, "raw").contiguous()
         zz, stride = ops._rows(z, n, "z_vals")
@@ -35,21 +35,23 @@ class _PenalizerFn(torch.autograd.Function):
         g = g_loss.reshape(1).float().contiguous()
         check(load().dmn_penalizer_bwd(ptr(raw), ptr(zz), stride, ptr(depth), ptr(rays_d), n, s, c, tolerance, deta_w,
                                        ptr(sums), ptr(g), ptr(g_raw), current_stream()), "dmn_penalizer_bwd")
-        return g_raw, None, None, None, None, None
+        return g_raw, None, None, None, None, None, None
 
 
-def emptiness_penalizer(raw, z_vals, depths, rays_d, tolerance, deta_w):
+def emptiness_penalizer(raw, z_vals, depths, rays_d, tolerance, deta_w, reduce=None):
     """``emptiness_penalizer(raw, z_vals, depths[N,1], rays_d, tolerance, deta_w)`` (networks/penalizer.py:5-55):
     scalar loss; gradient flows to ``raw[..., 4:]`` only (``depths`` is used as a constant, as the reference's
-    caller detaches it)."""
+    caller detaches it).  ``reduce`` (ray-sharded training, ``parallel.ShardReducer``): sums the kernel's four
+    partial sums over all shards, so that value and normalisers are the whole batch's; the gradient reaches this
+    shard's samples only (sum gradients over ranks)."""
     if raw.dim() != 3 or raw.shape[-1] < 5:
         raise ValueError("raw must be [N, S, 4 + ins_num + 1]")
     if z_vals.shape[1] != raw.shape[1]:
         raise ValueError("z_vals and raw disagree on the number of samples")
-    return _PenalizerFn.apply(raw, z_vals, depths.detach(), rays_d, float(tolerance), float(deta_w))
+    return _PenalizerFn.apply(raw, z_vals, depths.detach(), rays_d, float(tolerance), float(deta_w), reduce)
 
 
-def ins_penalizer(raw, z_vals, depth, rays_d, args):
+def ins_penalizer(raw, z_vals, depth, rays_d, args, reduce=None):
     """``ins_penalizer(raw, z_vals, depth[N], rays_d, args)`` with ``args.tolerance`` / ``args.deta_w``
     (networks/penalizer.py:58-62)."""
-    return emptiness_penalizer(raw, z_vals, depth[..., None].detach(), rays_d, args.tolerance, args.deta_w)
+    return emptiness_penalizer(raw, z_vals, depth[..., None].detach(), rays_d, args.tolerance, args.deta_w, reduce)

@@ -8,7 +8,7 @@ from typing import Dict
 import torch
 
 from . import ops
-from .autograd import CompositeFn, field_fn, needs_grad
+from .autograd import CompositeFn, FieldFn, needs_grad
 from .dm_nerf import DM_NeRF, Embedder
 from .helpers import _unit_linspace
 
@@ -58,7 +58,7 @@ def dm_nerf(rays, position_embedder, view_embedder, model_coarse, model_fine, z_
 
     def field(model, z, sigma_only=False):
         if train:       # outputs carry grad to the parameters (SURVEY.md section 8b "Autograd")
-            return field_fn().apply(rays_o, rays_d, z, model, precision, *model.parameters())
+            return FieldFn.apply(rays_o, rays_d, z, model, precision, *model.parameters())
         return ops.field_rays(rays_o, rays_d, z, model.blob(precision), model.ins_num, precision, sigma_only=sigma_only)
 
     # ``args.coarse_heads = False`` (set by render_image(image_only=True), inference in a split precision only): the

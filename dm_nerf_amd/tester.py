@@ -26,11 +26,13 @@ def render_image(position_embedder, view_embedder, model_coarse, model_fine, c2w
     (tester.py:70-76 keeps ``rgb_fine`` and ``ins_fine``); the returned images are bit-identical."""
     H, W, K = hwk
     chunk = int(chunk or args.N_test)
-    # The image loop defaults to the split-precision field kernel in its bf16 flavour: 7e-6 .. 2e-5 on raw against
-    # the reference (bar: 1e-4), 3.2x the exact kernel's speed, fp32's exponent range (nothing to guard).  "fp16x3"
-    # is ten times closer (1e-6) and 3 % slower; its range guard is checked per image below.
-    # dm_nerf() called directly stays on exact fp32 unless args.precision says otherwise.
-    precision = getattr(args, "precision", None) or "bf16x3"
+    # Reference arithmetic (exact fp32 products) unless the caller opts in: args.precision = "fp16x3" | "bf16x3" selects
+    # the split-precision field kernel (three 16-bit MFMAs per product, fp32 accumulate: 1e-6 / 7e-6 on raw against the
+    # reference, ~3x the rays/s).  Same default as dm_nerf().
+    precision = getattr(args, "precision", None) or "fp32"
+    if image_only and precision == "fp32":
+        raise ValueError("image_only (density-only coarse pass) is a mode of the split-precision kernels: set "
+                         "args.precision to 'fp16x3' or 'bf16x3'")
     if getattr(args, "precision", None) != precision or image_only:
         args = SimpleNamespace(**{**vars(args), "precision": precision, "coarse_heads": not image_only})
     if precision == "fp16x3":
@@ -55,7 +57,7 @@ def render_image(position_embedder, view_embedder, model_coarse, model_fine, c2w
         warnings.warn("dm_nerf_amd: fp16x3 range exceeded, re-rendering this image with precision='fp32'")
         exact = SimpleNamespace(**{**vars(args), "precision": "fp32"})
         return render_image(position_embedder, view_embedder, model_coarse, model_fine, c2w, hwk, exact,
-                            chunk=chunk, crop_mask=crop_mask, ray_range=ray_range, image_only=image_only)
+                            chunk=chunk, crop_mask=crop_mask, ray_range=ray_range)
     if ray_range is not None:
         return rgb, ins
     if crop_mask is not None:                                                    # tester.py:77-81

@@ -12,7 +12,7 @@ scipy Hungarian on the host as in the reference), both with the reference's sign
 functions plug in just as well.  Without them the step optimises the two colour terms only."""
 from __future__ import annotations
 
-from typing import Callable, Dict, Optional
+from typing import Callable, Dict, Optional, Tuple
 
 import torch
 
@@ -32,15 +32,20 @@ def decayed_lrate(i: int, lrate: float, lrate_decay: int) -> float:
 
 def train_step(i: int, batch_rays, target_rgb, nerf, z_vals_coarse, optimizer, lrate: float = 5e-4,
                lrate_decay: int = 500, ins_loss: Optional[Callable] = None, penalizer: Optional[Callable] = None,
-               allreduce: Optional[Callable] = None) -> Dict[str, float]:
+               allreduce: Optional[Callable] = None, shard: Optional[Tuple[int, int]] = None) -> Dict[str, float]:
     """One optimisation step (train_dmsr.py:32-72).  ``nerf`` is the tuple ``create_nerf`` returns.
-    ``allreduce(models)`` is called between backward and the optimizer step (data-parallel training:
-    ``dm_nerf_amd.parallel.allreduce_gradients``)."""
+    ``allreduce(models)`` is called between backward and the optimizer step (data-parallel training).
+
+    Ray-sharded, batch-exact step: pass ``shard=(rays of this rank, rays of the whole batch)``,
+    loss heads built with ``reduce=parallel.ShardReducer(group)`` and ``allreduce=lambda m: bucket.allreduce(group)``
+    (a SUM): the colour terms are weighted by the shard's share of the batch, the instance / emptiness terms see the
+    whole batch's statistics, so the summed gradient is that of the unsharded loss for shards of any sizes."""
     position_embedder, view_embedder, model_coarse, model_fine, args = nerf
     out = dm_nerf(batch_rays, position_embedder, view_embedder, model_coarse, model_fine, z_vals_coarse, args)
     mse_c = torch.mean((out["rgb_coarse"] - target_rgb) ** 2)                       # img2mse, evaluator.py:11
     mse_f = torch.mean((out["rgb_fine"] - target_rgb) ** 2)
-    total = mse_f + mse_c
+    share = 1.0 if shard is None else shard[0] / shard[1]          # mean over the batch = sum of share * mean over shard
+    total = (mse_f + mse_c) * share
     terms = {"rgb_coarse": mse_c, "rgb_fine": mse_f}
     if ins_loss is not None:                                                        # train_dmsr.py:38-45
         terms["ins_coarse"], terms["ins_fine"] = ins_loss(out["ins_coarse"]), ins_loss(out["ins_fine"])

@@ -305,8 +305,9 @@ def ins_criterion(pred_ins: torch.Tensor, gt_labels: torch.Tensor, ins_num: int)
 
 
 # --------------------------------------------------------------------------------------
-# object manipulation (row N3) -- restated from the text of networks/manipulator.py:18-83; the module itself
-# does not import in the build image (imageio / cv2 / lpips), so this restatement is NOT pinned by a reference run
+# object manipulation (row N3) -- networks/manipulator.py:18-205.  Pinned by G12: the reference's own four function
+# definitions, compiled from its source text in a namespace of torch / F / its sample_pdf (the module's top-level
+# imports need packages the image lacks; the functions do not), tests/golden/make_golden.py:g12_manipulator
 # --------------------------------------------------------------------------------------
 def exchanger(ori_raw: torch.Tensor, tar_raws, ori_raw_pred: torch.Tensor, tar_raw_preds, move_labels):
     """Label surgery between an original and a transformed scene.  Returns
@@ -328,6 +329,59 @@ def exchanger(ori_raw: torch.Tensor, tar_raws, ori_raw_pred: torch.Tensor, tar_r
         out = torch.where(take[..., None], tar_raw, out)                                           # :78-80
         out = torch.where(wipe[..., None], out * 0, out)                                           # :81
     return out, tar_raws, ori_point, tar_point
+
+
+def manipulator_depths(n_rays: int, near: float, far: float, n_samples: int) -> torch.Tensor:
+    """``z = near*(1-t) + far*t`` (networks/manipulator.py:116-120; not the same rounding as ``z_val_sample``)."""
+    lo, hi = near * torch.ones(n_rays, 1), far * torch.ones(n_rays, 1)
+    t = torch.linspace(0.0, 1.0, steps=n_samples)
+    return (lo * (1.0 - t) + hi * t).expand(n_rays, n_samples)
+
+
+def manipulator(coarse: Params, fine: Params, ori_rays: torch.Tensor, f_tar_rays, n_samples: int, n_importance: int,
+                near: float, far: float, move_labels, draws):
+    """Two-pass re-render of a scene with moved objects (networks/manipulator.py:137-205).  ``draws``: the uniform
+    draws of the ``2 + len(f_tar_rays)`` stochastic ``sample_pdf`` calls, in call order.  Returns
+    ``(final_rgb, final_ins, tar_rgb, tar_ins_accum)`` plus a dict of intermediates for stage-wise checks."""
+    draws = list(draws)
+
+    def resample(z, w):
+        mid = 0.5 * (z[..., 1:] + z[..., :-1])
+        return inverse_cdf(mid, w[..., 1:-1], n_importance, det=False, u=draws.pop(0))
+
+    def accum_labels(rays, z, z_new):
+        z_full = merge_depths(z, z_new)
+        raw_full = field_on_rays(fine, rays[0], rays[1], z_full)
+        return composite(raw_full, z_full, rays[1], manipulator=True)[3], z_full
+
+    n = ori_rays.shape[1]
+    ori_z = manipulator_depths(n, near, far, n_samples)
+    ori_raw = field_on_rays(coarse, ori_rays[0], ori_rays[1], ori_z)                       # :140-141
+    _, ori_w, _, _ = composite(ori_raw, ori_z, ori_rays[1], manipulator=True)              # :144
+    ori_acc, z_full_first = accum_labels(ori_rays, ori_z, resample(ori_z, ori_w))          # :147-152
+    tar_raws, tar_zs, tar_samples, tar_accs = [], [], [], []
+    tar_rgb = tar_acc = None
+    for tar_rays in f_tar_rays:                                                            # :155-176
+        tar_z = manipulator_depths(n, near, far, n_samples)
+        tar_raw = field_on_rays(coarse, tar_rays[0], tar_rays[1], tar_z)
+        tar_rgb, tar_w, _, _ = composite(tar_raw, tar_z, tar_rays[1], manipulator=True)
+        z_new = resample(tar_z, tar_w)
+        tar_acc, _ = accum_labels(tar_rays, tar_z, z_new)
+        tar_raws.append(tar_raw); tar_zs.append(tar_z); tar_samples.append(z_new); tar_accs.append(tar_acc)
+    ori_raw, _, ex1_ori, ex1_tar = exchanger(ori_raw, tar_raws, ori_acc, tar_accs, move_labels)   # :179
+    _, ori_w, _, _ = composite(ori_raw, ori_z, ori_rays[1], manipulator=True)              # :183
+    ori_new = resample(ori_z, ori_w)                                                       # :186-187
+    extra = torch.cat(tar_samples, -1)                                                     # :190
+    z_final = torch.sort(torch.cat([ori_z, ori_new, extra], -1), -1).values                # :191
+    ori_raw = field_on_rays(fine, ori_rays[0], ori_rays[1], z_final)                       # :194-195
+    for i, tar_rays in enumerate(f_tar_rays):                                              # :192-199
+        tar_z_all = torch.sort(torch.cat([tar_zs[i], ori_new, extra], -1), -1).values
+        tar_raws[i] = field_on_rays(fine, tar_rays[0], tar_rays[1], tar_z_all)
+    ori_raw, _, ex2_ori, ex2_tar = exchanger(ori_raw, tar_raws, ori_acc, tar_accs, move_labels)   # :201
+    final_rgb, _, _, final_ins = composite(ori_raw, z_final, ori_rays[1], manipulator=True)       # :203
+    trace = {"z_full_first": z_full_first, "z_final": z_final, "ex1_ori_label": ex1_ori, "ex1_tar_label": ex1_tar,
+             "ex2_ori_label": ex2_ori, "ex2_tar_label": ex2_tar}
+    return final_rgb, final_ins, tar_rgb, tar_acc, trace
 
 
 # --------------------------------------------------------------------------------------

@@ -203,3 +203,96 @@ def selector_case():
     unlabeled_pick = rng.choice(n_unlabeled, size=n_train - n_ins, replace=False)
     return dict(H=H, W=W, rgb=rgb, label=label, pose=pose, K=K, n_train=n_train, full_pick=full_pick,
                 crop_mask=crop_mask, ins_index=ins_index, labeled_pick=labeled_pick, unlabeled_pick=unlabeled_pick)
+
+
+# ---- G12: object manipulator (networks/manipulator.py:18-205) -------------------------------
+# tag -> (rays, samples, channels, moved labels, seed)
+EXCHANGE_CASES = {"a": (48, 64, 18, (3, 7), 55), "b": (12, 192, 98, (40,), 56), "c": (20, 100, 11, (2, 5, 0), 57)}
+
+
+def exchange_case(n: int, s: int, c: int, moves, seed: int):
+    """Per-point raw rows and per-ray composited logits of an original scene and of one transformed scene per moved
+    label, biased so that every branch of ``exchanger`` occurs (occluders, fillings, take, wipe, keep), with
+    saturated logits on a few points so that ``argmax(sigmoid(.))`` ties resolve to the first channel."""
+    rng = np.random.default_rng(seed)
+
+    def scene():
+        raw = (rng.standard_normal((n, s, c)) * 3).astype(np.float32)
+        for lab in moves:
+            raw[rng.random((n, s)) < 0.2, 4 + lab] += 9.0
+        raw[0, :8, 4:] = 40.0                                   # sigmoid saturates to 1.0 on every channel
+        pred = (rng.standard_normal((n, c - 4)) * 3).astype(np.float32)
+        for lab in moves:
+            pred[rng.random(n) < 0.3, lab] += 9.0
+        return raw, pred
+
+    ori_raw, ori_pred = scene()
+    tars = [scene() for _ in moves]
+    return ori_raw, ori_pred, [t[0] for t in tars], [t[1] for t in tars]
+
+
+def manipulator_params(ins_num: int, seed: int, jitter_seed=None):
+    """Seeded weights with a softer density and a louder instance head than ``make_params`` gives: rays then end at
+    depths 6.5 .. 8.5 with five different point labels along them, which the two-pass re-render needs to do anything.
+    ``jitter_seed``: add 2 % noise, so that a "fine" network agrees with the "coarse" one about the scene (as a
+    trained pair does) without being the same function."""
+    from dm_nerf_amd.synthetic import make_params
+    p = make_params(ins_num, seed, sharpen=False)
+    p["density_linear.weight"] = p["density_linear.weight"] * 12.0
+    p["ins_linear.weight"] = p["ins_linear.weight"] * 10.0
+    p["ins_feature_linear.weight"] = p["ins_feature_linear.weight"] * 3.0
+    if jitter_seed is not None:
+        import torch
+        rng = np.random.default_rng(jitter_seed)
+        for k in p:
+            noise = rng.standard_normal(tuple(p[k].shape)).astype(np.float32)
+            p[k] = p[k] + 0.02 * float(p[k].abs().max()) * torch.from_numpy(noise)
+    return p
+
+
+MANIPULATOR_NETS = ((0, None), (0, 5))      # (seed, jitter_seed) of the coarse and the fine network
+MANIPULATOR_LABELS = (1, 4)
+
+
+def manipulator_case(n_rays: int = 24, seed: int = 61):
+    """Original rays, one inversely transformed ray set per moved object (a translation; a translation plus a
+    rotation about the view axis), and the uniform draws of the 2 + len(labels) ``sample_pdf`` calls."""
+    o, d, _, _ = path_rays(n_rays, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    ca, sa = math.cos(0.1), math.sin(0.1)
+    rot = np.array([[ca, -sa, 0.0], [sa, ca, 0.0], [0.0, 0.0, 1.0]], dtype=np.float32)
+    tars = [(o + np.array([0.4, 0.0, 0.0], np.float32), d.copy()),
+            ((o + np.array([-0.3, 0.2, 0.0], np.float32)) @ rot.T, d @ rot.T)]
+    tars = [(a.astype(np.float32), b.astype(np.float32)) for a, b in tars]
+    draws = [rng.uniform(0, 1, size=(n_rays, N_IMPORTANCE)).astype(np.float32) for _ in range(2 + len(tars))]
+    return o, d, tars, draws
+
+
+# ---- BASELINE config 5: ScanNet full resolution --------------------------------------------
+SCANNET_H, SCANNET_W = 968, 1296                       # colour frames of a ScanNet scene (loader_scannet.py:98-99)
+SCANNET_CROP = (640, 480)                              # crop_width, crop_height (configs/test/scannet/scene0010_00.txt:13-14)
+SCANNET_NEAR, SCANNET_FAR = 0.0, 9.5                   # :17-18
+
+
+def scannet_intrinsics() -> np.ndarray:
+    """4x4 ``intrinsic_color.txt``-shaped matrix (values of a typical ScanNet colour camera)."""
+    return np.array([[1170.19, 0.0, 647.75, 0.0], [0.0, 1170.19, 483.75, 0.0], [0.0, 0.0, 1.0, 0.0],
+                     [0.0, 0.0, 0.0, 1.0]], dtype=np.float64)
+
+
+def scannet_crop_mask(H: int, W: int, crop_size) -> np.ndarray:
+    """The centre rectangle the ScanNet loader marks (datasets/loader_scannet.py:17-24 restated)."""
+    mask = np.zeros((H, W), dtype=np.int8)
+    new_w, new_h = crop_size
+    mh, mw = (H - new_h) // 2, (W - new_w) // 2
+    mask[mh:H - mh, mw:W - mw] = 1
+    return mask
+
+
+def scannet_pose(index: int) -> np.ndarray:
+    """Camera inside a room-sized volume, looking along +z with a small per-pose turn (OpenCV convention, K22 = 1)."""
+    a = 0.15 * index
+    c2w = np.eye(4, dtype=np.float32)
+    c2w[:3, :3] = np.array([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]], np.float32)
+    c2w[:3, 3] = (0.2 * index - 0.5, 0.1, -1.0)
+    return c2w

@@ -269,10 +269,99 @@ def g11_criterion():
     save("g11_criterion.npz", **out)
 
 
+def _reference_manipulator():
+    """The four hot-path functions of networks/manipulator.py:18-205, compiled from the reference's own source text.
+    The module does not import here (its top-level imports :3-15 need imageio / lpips / cv2 / skimage, absent from the
+    image), but these functions only touch ``torch``, ``F`` and the reference's ``sample_pdf`` -- so their definitions
+    are taken out of the parsed file and executed in a namespace holding exactly those; nothing is stubbed."""
+    import ast
+    import torch.nn.functional as F
+    path = os.path.join(REF, "networks", "manipulator.py")
+    wanted = ("exchanger", "manipulator_render", "manipulator_nerf", "manipulator")
+    tree = ast.parse(open(path).read(), filename=path)
+    body = [node for node in tree.body if isinstance(node, ast.FunctionDef) and node.name in wanted]
+    assert [node.name for node in body] == list(wanted)
+    ns = {"torch": torch, "F": F, "sample_pdf": ref_helpers.sample_pdf}
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+def g12_manipulator():
+    """exchanger / manipulator_render / manipulator_nerf / manipulator of the reference (row N3)."""
+    ns = _reference_manipulator()
+    out = {}
+    T = torch.from_numpy
+    # ---- exchanger: label surgery, edited in place
+    for tag, (n, s, c, moves, seed) in cases.EXCHANGE_CASES.items():
+        ori_raw, ori_pred, tar_raws, tar_preds = cases.exchange_case(n, s, c, moves, seed)
+        got_raw, _, ori_label, tar_label = ns["exchanger"](T(ori_raw.copy()), [T(t) for t in tar_raws], T(ori_pred),
+                                                           [T(t) for t in tar_preds], list(moves))
+        got = got_raw.numpy()
+        # where each output row came from: -1 zeroed, 0 kept, 1 + k taken from target k (first match; small, and with
+        # the digest of the full tensor it pins the result bit for bit)
+        src = np.zeros((n, s), np.int8)
+        for k, t in enumerate(tar_raws):
+            src[(src == 0) & (got == t).all(-1) & ~(got == ori_raw).all(-1)] = 1 + k
+        src[(got == 0).all(-1) & ~(ori_raw == 0).all(-1)] = -1
+        out.update({f"ex_{tag}_digest": cases.digest(ori_raw, ori_pred, *tar_raws, *tar_preds),
+                    f"ex_{tag}_out_digest": cases.digest(got), f"ex_{tag}_src": src,
+                    f"ex_{tag}_ori_label": ori_label.numpy().astype(np.int16),
+                    f"ex_{tag}_tar_label": tar_label.numpy().astype(np.int16)})
+    # ---- manipulator_render: compositing that keeps the air channel
+    for tag, (n, s, c, seed) in {"a": (32, 64, 18, 141), "b": (16, 192, 18, 142), "c": (8, 64, 98, 143),
+                                 "d": (8, 100, 11, 144)}.items():
+        raw, z, d = cases.composite_case(n, s, c, seed)
+        rgb, w, depth, ins = ns["manipulator_render"](T(raw), T(z), T(d))
+        out.update({f"mr_{tag}_rgb": rgb, f"mr_{tag}_w": w, f"mr_{tag}_depth": depth, f"mr_{tag}_ins": ins})
+    # ---- manipulator_nerf: lattice and raw rows; manipulator: the two-pass re-render with recorded draws
+    o, d, tars, draws = cases.manipulator_case()
+    pos_enc, _ = ref_model.get_embedder(10, 0)
+    dir_enc, _ = ref_model.get_embedder(4, 0)
+    nets = []
+    for seed, jitter in cases.MANIPULATOR_NETS:
+        net = ref_model.DM_NeRF(8, 256, 63, 27, [4], 13)
+        net.load_state_dict(cases.manipulator_params(13, seed, jitter))
+        nets.append(net.eval())
+    rays = T(np.stack([o, d], 0))
+    f_tar = [T(np.stack([a, b], 0)) for a, b in tars]
+    margs = SimpleNamespace(N_samples=cases.N_SAMPLES, N_importance=cases.N_IMPORTANCE, near=cases.NEAR, far=cases.FAR,
+                            target_label=list(cases.MANIPULATOR_LABELS))
+    with torch.no_grad():
+        raw, z = ns["manipulator_nerf"](rays[:, :6], pos_enc, dir_enc, nets[0], cases.N_SAMPLES, cases.NEAR, cases.FAR)
+        out.update({"mn_z_lattice": z[0], "mn_raw": raw})
+        raw2, z2 = ns["manipulator_nerf"](rays[:, :6], pos_enc, dir_enc, nets[1], z_vals=z[:, ::3] * 1.01)
+        out["mn_raw_given_z"] = raw2
+        trace = {"labels": [], "z": []}
+        inner_ex, inner_nerf = ns["exchanger"], ns["manipulator_nerf"]
+
+        def ex_spy(*a):
+            res = inner_ex(*a)
+            trace["labels"].append((res[2].numpy().astype(np.int16), res[3].numpy().astype(np.int16)))
+            return res
+
+        def nerf_spy(*a, **kw):
+            res = inner_nerf(*a, **kw)
+            trace["z"].append(res[1])
+            return res
+
+        ns["exchanger"], ns["manipulator_nerf"] = ex_spy, nerf_spy
+        with RandQueue([T(u) for u in draws]):
+            final_rgb, final_ins, tar_rgb, tar_acc = ns["manipulator"](pos_enc, dir_enc, nets[0], nets[1], rays, f_tar,
+                                                                      margs)
+        ns["exchanger"], ns["manipulator_nerf"] = inner_ex, inner_nerf
+    out.update({"mp_digest": cases.digest(o, d, *[x for t in tars for x in t], *draws),
+                "mp_final_rgb": final_rgb, "mp_final_ins": final_ins, "mp_tar_rgb": tar_rgb, "mp_tar_ins_accum": tar_acc,
+                "mp_ex1_ori_label": trace["labels"][0][0], "mp_ex1_tar_label": trace["labels"][0][1],
+                "mp_ex2_ori_label": trace["labels"][1][0], "mp_ex2_tar_label": trace["labels"][1][1],
+                "mp_z_full_first": trace["z"][1],        # original rays: 64 + 128 depths of pass 1
+                "mp_z_final": trace["z"][-2]})           # original rays: 64 + 128 + 128 * objects depths of pass 2
+    save("g12_manipulator.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     table = {"g1": g1_rays, "g2": g2_encode, "g3": g3_field, "g4": g4_composite, "g5": g5_sampler,
              "g6": g6_path, "g7": g7_gradients, "g8": g8_image, "g9": g9_selectors, "g10": g10_penalizer,
-             "g11": g11_criterion}
+             "g11": g11_criterion, "g12": g12_manipulator}
     for key in which:
         table[key]()

@@ -381,6 +381,102 @@ def test_replica_shape_config():
     assert rel_err(H(got["rgb_coarse"]), want["rgb_coarse"].numpy()) < 1e-4
 
 
+# ---- end-to-end deviation on a sample large enough to measure the sampler's flip RATE ---------------------------------
+# Observed on MI355X (this test's print, and bench.py's `deviation_vs_cpu_oracle` on 16384 rays): the fraction of rays
+# whose fine outputs leave 1e-4 is the same in all three arithmetics -- it is the rate at which the reference's sampler
+# flips on 1e-7 noise, not a property of the field kernel's precision.  Caps = 2x the observed rate.
+_FLIP_CAPS = {"fp32": (0.016, 0.021), "fp16x3": (0.016, 0.021), "bf16x3": (0.017, 0.022)}    # (rgb_fine, depth_fine)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3", "bf16x3"])
+def test_flip_rate_against_oracle_on_2048_rays(precision):
+    Hh = W = 800
+    n = 2048
+    pos, view, coarse, fine, args = nets(13, 0, 1)
+    args.precision = precision
+    K, c2w = oracle.dmsr_intrinsics(Hh, W), oracle.study_pose(0)
+    pick = torch.from_numpy(np.sort(np.random.default_rng(31).choice(Hh * W, size=n, replace=False)))
+    ro, rd = dm.get_rays_k(Hh, W, K, c2w)
+    rays = torch.stack([ro.reshape(-1, 3)[pick.to(DEV)], rd.reshape(-1, 3)[pick.to(DEV)]], 0)
+    z = dm.z_val_sample(n, args.near, args.far, 64)
+    with torch.no_grad():
+        got = dm.dm_nerf(rays, pos, view, coarse, fine, z, args)
+        want = oracle.render_rays(rays.cpu(), oracle.make_params(13, 0), oracle.make_params(13, 1),
+                                  oracle.coarse_depths(n, args.near, args.far, 64))
+    seen = {k: (_rays_off(H(got[k]), want[k].numpy()), rel_err(H(got[k]), want[k].numpy()))
+            for k in ("rgb_fine", "depth_fine", "ins_fine", "rgb_coarse", "depth_coarse", "ins_coarse")}
+    print(f"{precision}: (fraction of rays > 1e-4, worst) {seen}")
+    for k in ("rgb_coarse", "depth_coarse", "ins_coarse"):             # in front of the sampler: 1e-4 outright
+        assert seen[k][1] < 1e-4, (k, seen[k])
+    cap_rgb, cap_depth = _FLIP_CAPS[precision]
+    assert seen["rgb_fine"][0] <= cap_rgb and seen["depth_fine"][0] <= cap_depth, seen
+    assert seen["ins_fine"][0] <= 0.002, seen                           # the instance map is smooth in the depths
+    assert seen["rgb_fine"][1] < 4e-3 and seen["depth_fine"][1] < 6e-3  # one flipped draw = one bin (0.175 of 15)
+
+
+# ---- BASELINE config 5: ScanNet full-resolution render_path with the loader's crop mask, image-sharded ----------
+def test_scannet_full_resolution_render_with_crop_mask():
+    """968x1296 ScanNet colour intrinsics (4x4 matrix), near 0 / far 9.5, through render_test(..., crop_mask=...) as
+    test_scannet.py:20-22 calls it: 19 chunks of 65536 rays + a ragged tail of 9344; the crop branch of
+    tester.py:77-81 (select the mask's pixels, reshape to crop_height x crop_width) must be the centre rectangle of
+    the full image bit for bit, and a sample of rays must match the CPU oracle."""
+    Hh, W = cases.SCANNET_H, cases.SCANNET_W
+    K = cases.scannet_intrinsics()
+    ins_num = 22
+    pos, view, coarse, fine, args = nets(ins_num, 3, 5)
+    args.near, args.far = cases.SCANNET_NEAR, cases.SCANNET_FAR
+    args.crop_width, args.crop_height = cases.SCANNET_CROP
+    mask = cases.scannet_crop_mask(Hh, W, cases.SCANNET_CROP)
+    assert int(mask.sum()) == 640 * 480 and (Hh * W) % 65536 == 9344
+    pose = cases.scannet_pose(1)
+    rgbs, inss, _ = dm.render_test(pos, view, coarse, fine, [pose], [Hh, W, K], args, crop_mask=mask, chunk=65536)
+    assert rgbs[0].shape == (480, 640, 3) and inss[0].shape == (480, 640, ins_num)
+    full_rgb, full_ins = dm.render_image(pos, view, coarse, fine, pose, [Hh, W, K], args, chunk=65536)
+    assert full_rgb.shape == (Hh, W, 3)
+    mh, mw = (Hh - 480) // 2, (W - 640) // 2
+    np.testing.assert_array_equal(H(rgbs[0]), H(full_rgb[mh:Hh - mh, mw:W - mw]))
+    np.testing.assert_array_equal(H(inss[0]), H(full_ins[mh:Hh - mh, mw:W - mw]))
+    # flat mask (what the reference's indexing of [H*W, 3] needs) gives the same
+    rgbs2, _, _ = dm.render_test(pos, view, coarse, fine, [pose], [Hh, W, K], args, crop_mask=mask.reshape(-1),
+                                 chunk=4096 * 64)
+    np.testing.assert_array_equal(H(rgbs2[0]), H(rgbs[0]))                       # chunking-invariant, too
+    # a sample of rays (incl. the last pixels, which sit in the ragged tail) against the oracle
+    pick = np.concatenate([np.random.default_rng(12).choice(Hh * W, size=60, replace=False),
+                           np.arange(Hh * W - 4, Hh * W)])
+    oo, od = oracle.rays_from_camera(Hh, W, K, torch.from_numpy(pose))
+    rays = torch.stack([oo.reshape(-1, 3)[pick], od.reshape(-1, 3)[pick]], 0).float()
+    with torch.no_grad():
+        want = oracle.render_rays(rays, oracle.make_params(ins_num, 3), oracle.make_params(ins_num, 5),
+                                  oracle.coarse_depths(len(pick), args.near, args.far, 64))
+    got_rgb, got_ins = H(full_rgb).reshape(-1, 3)[pick], H(full_ins).reshape(-1, ins_num)[pick]
+    print("scannet sample: rays off", _rays_off(got_rgb, want["rgb_fine"].numpy()), _rays_off(got_ins, want["ins_fine"].numpy()),
+          "worst", rel_err(got_rgb, want["rgb_fine"].numpy()), rel_err(got_ins, want["ins_fine"].numpy()))
+    assert _rays_off(got_rgb, want["rgb_fine"].numpy()) <= 0.05 and rel_err(got_rgb, want["rgb_fine"].numpy()) < 2e-3
+    assert _rays_off(got_ins, want["ins_fine"].numpy()) <= 0.05 and rel_err(got_ins, want["ins_fine"].numpy()) < 2e-3
+
+
+def test_pose_sharded_render_path_over_eight_poses():
+    """Image-sharded rendering of config 5: the 8 poses dealt to 1, 2 and 8 ranks with parallel.pose_shard; every pose
+    is rendered exactly once and a rank's images do not depend on which other poses it renders."""
+    from dm_nerf_amd.parallel import pose_shard
+    Hh, W = 30, 40
+    K = cases.scannet_intrinsics().copy()
+    K[:2, :3] *= W / cases.SCANNET_W
+    pos, view, coarse, fine, args = nets(22, 3, 5)
+    args.near, args.far, args.N_test = cases.SCANNET_NEAR, cases.SCANNET_FAR, 500
+    poses = [cases.scannet_pose(i) for i in range(8)]
+    whole, _, _ = dm.render_test(pos, view, coarse, fine, poses, [Hh, W, K], args)
+    for world in (2, 8):
+        seen = []
+        for rank in range(world):
+            mine = pose_shard(len(poses), rank, world)
+            seen += mine
+            rgbs, _, _ = dm.render_test(pos, view, coarse, fine, [poses[i] for i in mine], [Hh, W, K], args)
+            for i, img in zip(mine, rgbs):
+                np.testing.assert_array_equal(H(img), H(whole[i]))
+        assert sorted(seen) == list(range(8))
+
+
 # ---- split-precision field kernels (3 x 16-bit MFMA per product) -------------------------------------
 @pytest.mark.parametrize("precision,tol", [("fp16x3", 2e-5), ("bf16x3", 1e-4)])
 @pytest.mark.parametrize("ins_num,seed", [(13, 0), (93, 3), (7, 4)])
@@ -592,7 +688,7 @@ def test_fine_stage_gradients_on_golden_depths(golden):
 def _min_abs_preactivation(net, o, d, z):
     """Smallest |pre-activation| over all ReLU units per sample point (torch ops on the device, dm_nerf.py:80-106)."""
     import torch.nn.functional as F
-    from dm_nerf_amd.autograd import _encode
+    from library_backward import _encode
     p = dict(net.named_parameters())
     with torch.no_grad():
         view = d / torch.norm(d, dim=-1, keepdim=True)
@@ -623,7 +719,8 @@ def test_field_backward_kernels_match_library_gemm_backward(ins_num, n, s, fwd, 
     """HIP backward (save record -> backward-data kernel -> split-K weight-gradient kernel) against autograd
     through library GEMMs on the device, every parameter of the network, ragged point counts, 1..3 logit tiles."""
     from dm_nerf_amd import autograd
-    from dm_nerf_amd.autograd import FieldFn, FieldFnLibrary
+    from dm_nerf_amd.autograd import FieldFn
+    from library_backward import FieldFnLibrary
     monkeypatch.setattr(autograd, "WGRAD_PRECISION", wgrad)
     monkeypatch.setattr(autograd, "DATA_PRECISION", data)
     _, _, net, _, _ = nets(ins_num, 3, 4)
@@ -741,6 +838,106 @@ def test_ins_criterion_matches_reference_golden(golden):
         np.testing.assert_allclose(got[2:], want[2:], rtol=2e-5, atol=2e-6 * np.abs(want[2:]).max())   # unsaturated rows
 
 
+# ---- ray-sharded training is batch-exact ----------------------------------------------
+class _TwoShardReducer:
+    """Single-process stand-in for parallel.ShardReducer: pass 1 records what a shard would contribute, pass 2 returns
+    own + the other shard's recording (detached: the other rank's backward is its own business)."""
+
+    def __init__(self, known=None):
+        self.own, self.other, self.calls, self.known = [], None, 0, known or {}
+
+    def __call__(self, tag, t):
+        if self.other is None:
+            self.own.append((tag, t.detach().clone()))
+            # the label set shapes the statistics (one row per label present anywhere): the recording pass must
+            # already see the whole batch's
+            return self.known[tag].to(t.device) if tag in self.known else t
+        tag2, rec = self.other[self.calls]
+        assert tag2 == tag
+        self.calls += 1
+        return t + rec
+
+
+def test_sharded_loss_heads_reproduce_the_unsharded_loss_and_gradient():
+    """ins_criterion and ins_penalizer on two unequal ray shards with their batch statistics summed (what
+    parallel.ShardReducer's all-reduce does): every shard computes the unsharded loss VALUE, and the shards' gradients
+    together are the unsharded gradient -- the Hungarian matching sees the whole batch's cost matrices and the label
+    set of the whole batch (one label occurs in shard B only), the penalizer the whole batch's mask sums."""
+    n, ins_num, cut = 96, 13, 41
+    pred, labels = cases.criterion_case(n, ins_num, (0, 2, 3, 7, 12), 311)
+    labels[:cut][labels[:cut] == 12] = 7                                     # label 12 is absent from shard A
+    assert 12 in labels[cut:] and 12 not in labels[:cut]
+    raw, z, depth, d = cases.penalizer_case(n, 64, 18, 301)
+    pargs = SimpleNamespace(tolerance=0.3, deta_w=0.2)
+    lab = torch.from_numpy(labels).to(DEV)
+
+    def losses(sl, reduce):
+        p = G(pred[sl]).requires_grad_(True)
+        r = G(raw[sl]).requires_grad_(True)
+        ins = dm.ins_criterion(p, lab[sl], ins_num, reduce=reduce)[0]
+        pen = dm.ins_penalizer(r, G(z[sl]), G(depth[sl]), G(d[sl]), pargs, reduce=reduce)
+        (ins + pen).backward()
+        return float(ins), float(pen), H(p.grad), H(r.grad)
+
+    whole = losses(slice(0, n), None)
+    shards = (slice(0, cut), slice(cut, n))
+    rec = []
+    known = {"ins_label_count": torch.bincount(torch.from_numpy(labels), minlength=ins_num + 1).float(),
+             "ins_ray_count": torch.tensor([float(n)])}
+    for sl in shards:                                                        # pass 1: what each shard contributes
+        r = _TwoShardReducer(known)
+        losses(sl, r)
+        rec.append(r.own)
+    got = []
+    for k, sl in enumerate(shards):                                          # pass 2: with the other shard's sums
+        r = _TwoShardReducer()
+        r.other = rec[1 - k]
+        got.append(losses(sl, r))
+        assert r.calls == len(rec[1 - k])
+    for k in range(2):                                                       # the loss values are the whole batch's
+        assert abs(got[k][0] - whole[0]) < 2e-6 * abs(whole[0]), (got[k][0], whole[0])
+        assert abs(got[k][1] - whole[1]) < 2e-6 * abs(whole[1]), (got[k][1], whole[1])
+    g_pred = np.concatenate([got[0][2], got[1][2]], 0)
+    g_raw = np.concatenate([got[0][3], got[1][3]], 0)
+    assert rel_err(g_pred, whole[2]) < 2e-6 and rel_err(g_raw, whole[3]) < 2e-6
+    # and without the reduction the shards optimise something else (what round 1 did)
+    alone = losses(shards[0], None)
+    assert abs(alone[0] - whole[0]) > 1e-3 * abs(whole[0])
+
+
+def test_grad_bucket_receives_the_weight_gradients_in_place():
+    """parallel.GradBucket: the weight-gradient kernel of both networks writes straight into the persistent flat
+    buffer, p.grad are views of it after backward (nothing to concatenate or copy back), and the values equal a
+    bucket-less backward."""
+    from dm_nerf_amd.parallel import GradBucket
+    pos, view, coarse, fine, args = nets(13, 0, 1)
+    coarse.train(); fine.train()
+    o, d, t_rand, u = cases.path_rays(32, seed=23)
+    args = SimpleNamespace(**{**vars(args), "perturb": 1.0, "is_train": True, "t_rand": G(t_rand), "u": G(u)})
+    z = dm.z_val_sample(32, cases.NEAR, cases.FAR, 64)
+
+    def backward():
+        out = dm.dm_nerf(G(np.stack([o, d], 0)), pos, view, coarse, fine, z, args)
+        (out["rgb_fine"].sum() + out["rgb_coarse"].sum() + out["ins_fine"].sum()).backward()
+
+    backward()
+    plain = torch.cat([p.grad.reshape(-1) for m in (coarse, fine) for p in m.parameters()]).clone()
+    bucket = GradBucket([coarse, fine])
+    for step in range(2):                                                    # buffer reuse across steps
+        for m in (coarse, fine):
+            for p in m.parameters():
+                p.grad = None
+        bucket.flat.fill_(float("nan"))                                      # every entry must be overwritten
+        backward()
+        in_place = [p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views)]
+        assert all(in_place), f"{sum(in_place)} of {len(in_place)} gradients live in the bucket"
+        np.testing.assert_array_equal(H(bucket.flat), H(plain))
+    with pytest.raises(RuntimeError, match="save record is released"):
+        raw = dm.autograd.FieldFn.apply(G(o), G(d), z, coarse, "fp32", *coarse.parameters())
+        raw.sum().backward(retain_graph=True)
+        raw.sum().backward()
+
+
 # ---- training ray selectors (row N1) --------------------------------------------------------------------
 def test_ray_selectors_match_reference_golden(golden):
     g = golden("g9_selectors.npz")
@@ -790,56 +987,116 @@ def test_image_only_coarse_pass_gives_bit_identical_images(precision):
         ops.field_rays(G(o), G(d), z, coarse.blob("fp32"), 13, "fp32", sigma_only=True)
 
 
-# ---- object manipulation (row N3) ---------------------------------------------------------------------------
-def test_exchanger_matches_the_restated_label_surgery():
-    """exchanger() against the oracle's restatement of networks/manipulator.py:18-83 (the reference module does not
-    import here: unpinned).  Two moved objects, labels biased so that every branch occurs: occluders, fillings, take,
-    wipe, keep; saturated logits so that the sigmoid's ties matter."""
-    rng = np.random.default_rng(55)
-    n, s, c = 48, 64, 18
-    def scene(seed_shift):
-        raw = (rng.standard_normal((n, s, c)) * 3).astype(np.float32)
-        for lab in (3, 7):
-            hit = rng.random((n, s)) < 0.2
-            raw[hit, 4 + lab] += 9.0
-        raw[0, :8, 4:] = 40.0                                   # all logits saturate: argmax(sigmoid) = first channel
-        pred = (rng.standard_normal((n, c - 4)) * 3).astype(np.float32)
-        pred[rng.random(n) < 0.3, 3] += 9.0
-        pred[rng.random(n) < 0.3, 7] += 9.0
-        return raw, pred
-    ori_raw, ori_pred = scene(0)
-    tars = [scene(1), scene(2)]
-    moves = [3, 7]
-    want_raw, _, want_ol, want_tl = oracle.exchanger(torch.from_numpy(ori_raw), [torch.from_numpy(t[0]) for t in tars],
-                                                     torch.from_numpy(ori_pred), [torch.from_numpy(t[1]) for t in tars],
-                                                     moves)
+# ---- object manipulation (row N3), pinned by the reference's own functions (G12) ------------------------------
+@pytest.mark.parametrize("tag", sorted(cases.EXCHANGE_CASES))
+def test_exchanger_is_bit_equal_to_the_reference(golden, tag):
+    """exchanger() against networks/manipulator.py:18-83 run on the same inputs: two / one / three moved objects
+    (one label that never occurs), C = 18 / 98 / 11, every branch (occluders, fillings, take, wipe, keep), saturated
+    logits so that the sigmoid's ties matter.  Labels, and every byte of the edited tensor."""
+    g = golden("g12_manipulator.npz")
+    n, s, c, moves, seed = cases.EXCHANGE_CASES[tag]
+    ori_raw, ori_pred, tar_raws, tar_preds = cases.exchange_case(n, s, c, moves, seed)
+    assert str(g[f"ex_{tag}_digest"]) == cases.digest(ori_raw, ori_pred, *tar_raws, *tar_preds)
     got = G(ori_raw)
-    out_raw, _, ol, tl = dm.exchanger(got, [G(t[0]) for t in tars], G(ori_pred), [G(t[1]) for t in tars], moves)
+    out_raw, _, ol, tl = dm.exchanger(got, [G(t) for t in tar_raws], G(ori_pred), [G(t) for t in tar_preds], list(moves))
     assert out_raw.data_ptr() == got.data_ptr()                 # edited in place, like the reference
-    np.testing.assert_array_equal(H(ol), want_ol.numpy())
-    np.testing.assert_array_equal(H(tl), want_tl.numpy())
-    np.testing.assert_array_equal(H(out_raw), want_raw.numpy())
-    changed = (want_raw.numpy() != ori_raw).any(-1)
-    wiped = (want_raw.numpy() == 0).all(-1)
-    assert 0.05 < changed.mean() < 0.95 and wiped.any() and (changed & ~wiped).any()
+    np.testing.assert_array_equal(H(ol), g[f"ex_{tag}_ori_label"])
+    np.testing.assert_array_equal(H(tl), g[f"ex_{tag}_tar_label"])
+    assert ol.dtype == torch.int64 and tl.dtype == torch.int64
+    assert cases.digest(H(out_raw)) == str(g[f"ex_{tag}_out_digest"])
+    src = g[f"ex_{tag}_src"]
+    np.testing.assert_array_equal(H(out_raw)[src == -1], 0.0)
+    for k, t in enumerate(tar_raws):
+        np.testing.assert_array_equal(H(out_raw)[src == 1 + k], t[src == 1 + k])
 
 
-def test_manipulator_two_pass_rerender_runs_on_the_kernels():
-    """manipulator() (networks/manipulator.py:136-205): identity 'move' of an object must reproduce the plain
-    re-render wherever labels agree; here: shapes, finiteness and determinism under fixed draws."""
+def test_manipulator_render_and_nerf_match_the_reference(golden):
+    g = golden("g12_manipulator.npz")
+    for tag, (n, s, c, seed) in {"a": (32, 64, 18, 141), "b": (16, 192, 18, 142), "c": (8, 64, 98, 143),
+                                 "d": (8, 100, 11, 144)}.items():
+        raw, z, d = cases.composite_case(n, s, c, seed)
+        got = dm.manipulator_render(G(raw), G(z), G(d))
+        for name, val in zip(("rgb", "w", "depth", "ins"), got):
+            assert val.shape == g[f"mr_{tag}_{name}"].shape
+            assert rel_err(H(val), g[f"mr_{tag}_{name}"]) < 5e-6, (tag, name)
+    o, d, _, _ = cases.manipulator_case()
     pos, view, coarse, fine, args = nets(13, 0, 1)
-    o, d, _, _ = cases.path_rays(40, seed=61)
+    coarse.load_state_dict(cases.manipulator_params(13, *cases.MANIPULATOR_NETS[0]))
+    fine.load_state_dict(cases.manipulator_params(13, *cases.MANIPULATOR_NETS[1]))
+    rays = G(np.stack([o, d], 0))[:, :6]
+    with torch.no_grad():
+        raw, z = dm.manipulator_nerf(rays, pos, view, coarse, cases.N_SAMPLES, cases.NEAR, cases.FAR)
+        np.testing.assert_array_equal(H(z[0]), g["mn_z_lattice"])           # near*(1-t) + far*t, not z_val_sample's
+        assert z.shape == (6, 64) and rel_err(H(raw), g["mn_raw"]) < 1e-5
+        raw2, z2 = dm.manipulator_nerf(rays, pos, view, fine, z_vals=(z[:, ::3] * 1.01).contiguous())
+        assert rel_err(H(raw2), g["mn_raw_given_z"]) < 1e-5
+
+
+def test_manipulator_two_pass_rerender_matches_the_reference(golden):
+    """manipulator() (networks/manipulator.py:137-205) with the reference's recorded torch.rand draws: two moved
+    objects, labels 1 and 4.  Point labels of both exchanges, the merged depths of both passes and the four returned
+    maps.  Like dm_nerf's fine outputs the result sits behind two stochastic resamplings and, here, behind argmax
+    label decisions, so a ray can leave 1e-4 when one of its points changes label on rounding noise: the labels are
+    held to >= 99.5 % agreement, the maps to 1e-4 on the rays whose labels all agree."""
+    g = golden("g12_manipulator.npz")
+    o, d, tars, draws = cases.manipulator_case()
+    pos, view, coarse, fine, args = nets(13, 0, 1)
+    coarse.load_state_dict(cases.manipulator_params(13, *cases.MANIPULATOR_NETS[0]))
+    fine.load_state_dict(cases.manipulator_params(13, *cases.MANIPULATOR_NETS[1]))
     rays = G(np.stack([o, d], 0))
-    shifted = torch.stack([rays[0] + torch.tensor([0.3, 0.0, 0.0], device=DEV), rays[1]], 0)
-    margs = SimpleNamespace(N_samples=64, N_importance=128, near=cases.NEAR, far=cases.FAR, target_label=[2])
+    f_tar = [G(np.stack([a, b], 0)) for a, b in tars]
+    margs = SimpleNamespace(N_samples=cases.N_SAMPLES, N_importance=cases.N_IMPORTANCE, near=cases.NEAR, far=cases.FAR,
+                            target_label=list(cases.MANIPULATOR_LABELS), u_draws=[G(u) for u in draws])
+    trace = {"labels": [], "z": []}
+    import sys
+    mod = sys.modules["dm_nerf_amd.manipulator"]            # the package attribute of that name is the function
+    inner_ex, inner_nerf = mod.exchanger, mod.manipulator_nerf
+
+    def ex_spy(*a):
+        res = inner_ex(*a)
+        trace["labels"].append((H(res[2]), H(res[3])))
+        return res
+
+    def nerf_spy(*a, **kw):
+        res = inner_nerf(*a, **kw)
+        trace["z"].append(H(res[1]))
+        return res
+
+    mod.exchanger, mod.manipulator_nerf = ex_spy, nerf_spy
+    try:
+        rgb, ins, tar_rgb, tar_acc = dm.manipulator(pos, view, coarse, fine, rays, f_tar, margs)
+    finally:
+        mod.exchanger, mod.manipulator_nerf = inner_ex, inner_nerf
+    assert rgb.shape == (24, 3) and ins.shape == (24, 14) and tar_rgb.shape == (24, 3) and tar_acc.shape == (24, 14)
+    # pass 1: lattice exchange (no resampling in front of it)
+    np.testing.assert_array_equal(trace["labels"][0][0], g["mp_ex1_ori_label"])
+    np.testing.assert_array_equal(trace["labels"][0][1], g["mp_ex1_tar_label"])
+    z_first, z_final = trace["z"][1], trace["z"][-2]
+    assert z_final.shape == (24, 64 + 128 * 3) and np.all(np.diff(z_final, axis=-1) >= 0)
+    off1 = np.mean(np.abs(z_first - g["mp_z_full_first"]) > 1e-4 * cases.FAR)
+    off2 = np.mean(np.abs(z_final - g["mp_z_final"]) > 1e-4 * cases.FAR)
+    agree = [float(np.mean(trace["labels"][1][k] == g[key])) for k, key in ((0, "mp_ex2_ori_label"), (1, "mp_ex2_tar_label"))]
+    ray_ok = (trace["labels"][1][0] == g["mp_ex2_ori_label"]).all(-1) & (np.abs(z_final - g["mp_z_final"]) < 1e-3).all(-1)
+    errs = {}
+    for got, key in ((rgb, "mp_final_rgb"), (ins, "mp_final_ins"), (tar_rgb, "mp_tar_rgb"), (tar_acc, "mp_tar_ins_accum")):
+        diff = np.abs(H(got) - g[key]).reshape(24, -1).max(-1) / np.abs(g[key]).max()
+        errs[key] = (float(diff[ray_ok].max()) if ray_ok.any() else 0.0, float(diff.max()), float((diff > 1e-4).mean()))
+    print(f"manipulator: depths off {off1:.4f} / {off2:.4f}, pass-2 labels agree {agree}, rays with all labels equal "
+          f"{ray_ok.mean():.3f}, (err on those, err on all, rays > 1e-4): {errs}")
+    assert off1 <= 0.01 and off2 <= 0.01
+    assert min(agree) >= 0.995
+    assert ray_ok.mean() >= 0.75
+    for key, (e_ok, e_all, frac) in errs.items():
+        assert e_ok < 1e-4, (key, e_ok)
+    assert rel_err(H(tar_rgb), g["mp_tar_rgb"]) < 1e-4          # coarse pass of the last object: no resampling involved
+    # own draws: deterministic under a fixed seed
+    margs.u_draws = None
     torch.manual_seed(5)
-    rgb, ins, tar_rgb, tar_acc = dm.manipulator(pos, view, coarse, fine, rays, [shifted], margs)
-    assert rgb.shape == (40, 3) and ins.shape == (40, 14) and tar_rgb.shape == (40, 3) and tar_acc.shape == (40, 14)
-    assert all(np.isfinite(H(t)).all() for t in (rgb, ins, tar_rgb, tar_acc))
+    a = dm.manipulator(pos, view, coarse, fine, rays, f_tar, margs)
     torch.manual_seed(5)
-    rgb2, ins2, _, _ = dm.manipulator(pos, view, coarse, fine, rays, [shifted], margs)
-    np.testing.assert_array_equal(H(rgb), H(rgb2))
-    np.testing.assert_array_equal(H(ins), H(ins2))
+    b = dm.manipulator(pos, view, coarse, fine, rays, f_tar, margs)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(H(x), H(y))
 
 
 # ---- the one-call C entry for a chunk ----------------------------------------------------------------------

@@ -195,3 +195,51 @@ def test_ins_criterion_restatement_matches_reference_golden(golden):
         for name, got in (("total", total), ("ce", ce), ("inv", inv), ("siou", siou)):
             np.testing.assert_allclose(float(got.detach()), float(g[f"{tag}_{name}"]), rtol=1e-6, atol=1e-9)
         np.testing.assert_allclose(pred_t.grad.numpy(), g[f"{tag}_grad"], rtol=1e-5, atol=1e-3)
+
+
+def test_g12_manipulator(golden):
+    """Row N3 against the reference's own functions (G12): exchanger bit for bit (labels, source of every output row,
+    digest of the edited tensor), manipulator_render, the manipulator lattice and field rows, and the two-pass
+    re-render with the recorded draws."""
+    g = golden("g12_manipulator.npz")
+    for tag, (n, s, c, moves, seed) in cases.EXCHANGE_CASES.items():
+        ori_raw, ori_pred, tar_raws, tar_preds = cases.exchange_case(n, s, c, moves, seed)
+        assert str(g[f"ex_{tag}_digest"]) == cases.digest(ori_raw, ori_pred, *tar_raws, *tar_preds)
+        out, _, ori_label, tar_label = oracle.exchanger(T(ori_raw), [T(t) for t in tar_raws], T(ori_pred),
+                                                        [T(t) for t in tar_preds], list(moves))
+        np.testing.assert_array_equal(ori_label.numpy(), g[f"ex_{tag}_ori_label"])
+        np.testing.assert_array_equal(tar_label.numpy(), g[f"ex_{tag}_tar_label"])
+        assert cases.digest(out.numpy()) == str(g[f"ex_{tag}_out_digest"]), tag
+        src = g[f"ex_{tag}_src"]
+        assert (src == -1).any() and (src == 0).any() and (src >= 1).any()        # every kind of row occurs
+        np.testing.assert_array_equal(out.numpy()[src == -1], 0.0)
+        for k, t in enumerate(tar_raws):
+            np.testing.assert_array_equal(out.numpy()[src == 1 + k], t[src == 1 + k])
+    for tag, (n, s, c, seed) in {"a": (32, 64, 18, 141), "b": (16, 192, 18, 142), "c": (8, 64, 98, 143),
+                                 "d": (8, 100, 11, 144)}.items():
+        raw, z, d = cases.composite_case(n, s, c, seed)
+        got = oracle.composite(T(raw), T(z), T(d), manipulator=True)
+        for name, val in zip(("rgb", "w", "depth", "ins"), got):
+            np.testing.assert_allclose(val.numpy(), g[f"mr_{tag}_{name}"], rtol=0, atol=1e-6, err_msg=f"{tag} {name}")
+    o, d, tars, draws = cases.manipulator_case()
+    assert str(g["mp_digest"]) == cases.digest(o, d, *[x for t in tars for x in t], *draws)
+    coarse, fine = (cases.manipulator_params(13, seed, jit) for seed, jit in cases.MANIPULATOR_NETS)
+    z = oracle.manipulator_depths(6, cases.NEAR, cases.FAR, cases.N_SAMPLES)
+    np.testing.assert_array_equal(z[0].numpy(), g["mn_z_lattice"])
+    with torch.no_grad():
+        raw = oracle.field_on_rays(coarse, T(o[:6]), T(d[:6]), z)
+        assert rel_err(raw.numpy(), g["mn_raw"]) < 2e-6
+        raw2 = oracle.field_on_rays(fine, T(o[:6]), T(d[:6]), z[:, ::3] * 1.01)
+        assert rel_err(raw2.numpy(), g["mn_raw_given_z"]) < 2e-6
+        rays = T(np.stack([o, d], 0))
+        f_tar = [T(np.stack([a, b], 0)) for a, b in tars]
+        rgb, ins, tar_rgb, tar_acc, trace = oracle.manipulator(coarse, fine, rays, f_tar, cases.N_SAMPLES,
+                                                               cases.N_IMPORTANCE, cases.NEAR, cases.FAR,
+                                                               list(cases.MANIPULATOR_LABELS), [T(u) for u in draws])
+    for k in ("ex1_ori_label", "ex1_tar_label", "ex2_ori_label", "ex2_tar_label"):
+        np.testing.assert_array_equal(trace[k].numpy(), g[f"mp_{k}"], err_msg=k)
+    np.testing.assert_allclose(trace["z_full_first"].numpy(), g["mp_z_full_first"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(trace["z_final"].numpy(), g["mp_z_final"], rtol=0, atol=2e-6)
+    for got, key in ((rgb, "mp_final_rgb"), (ins, "mp_final_ins"), (tar_rgb, "mp_tar_rgb"), (tar_acc, "mp_tar_ins_accum")):
+        assert got.shape == g[key].shape
+        assert rel_err(got.numpy(), g[key]) < 2e-6, key

@@ -109,3 +109,71 @@ def test_flat_gradient_allreduce_two_ranks(tmp_path):
     for a0, a1, l0, l1 in zip(r0["after"], r1["after"], r0["local"], r1["local"]):
         torch.testing.assert_close(a0, a1, rtol=0, atol=0)          # every rank holds the same reduced gradient
         torch.testing.assert_close(a0, (l0 + l1) / 2)               # the mean of the per-rank gradients
+
+
+# ---- batch-exact sharded loss: statistics all-reduce + shard-weighted gradient SUM --------------------------------
+def _toy_loss(pred, labels, n_classes, reduce, share):
+    """Same shape of computation as the sharded instance / colour losses: class-wise sums of a function of the
+    predictions (all-reduced), a loss that is NON-linear in those sums and normalised by the batch's ray count, plus a
+    mean-type term weighted by the shard's share."""
+    onehot = torch.nn.functional.one_hot(labels, n_classes).float()
+    stats = onehot.t() @ torch.log(pred + 1e-3)                       # [classes, K] sums over rays
+    count = onehot.sum(0)
+    n = torch.tensor([float(pred.shape[0])])
+    if reduce is not None:
+        stats, count, n = reduce("stats", stats), reduce("count", count), reduce("n", n)
+    matched = (stats / n).exp().sum() / (count > 0).sum()
+    return matched + share * (pred ** 2).mean()
+
+
+def _exact_worker(rank, world, port, result_path):
+    from dm_nerf_amd.parallel import GradBucket, ShardReducer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.Sigmoid(), torch.nn.Linear(8, 4), torch.nn.Sigmoid())
+        g = torch.Generator().manual_seed(1)
+        x, labels = torch.rand(37, 6, generator=g), torch.randint(0, 5, (37,), generator=g)
+        lo, hi = ray_shard(37, rank, world)                            # unequal shards: 19 + 18
+        bucket = GradBucket([net])
+        loss = _toy_loss(net(x[lo:hi]), labels[lo:hi], 5, ShardReducer(), (hi - lo) / 37)
+        loss.backward()
+        n = bucket.allreduce(scale=1.0)
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views))
+        # a second step reuses the buffer: grads dropped (set_to_none), backward again, same result
+        first = bucket.flat.clone()
+        for p in net.parameters():
+            p.grad = None
+        _toy_loss(net(x[lo:hi]), labels[lo:hi], 5, ShardReducer(), (hi - lo) / 37).backward()
+        bucket.allreduce(scale=1.0)
+        torch.save({"n": n, "flat": bucket.flat.clone(), "first": first, "loss": loss.detach()}, f"{result_path}.{rank}")
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_statistics_give_the_unsharded_loss_and_gradient(tmp_path):
+    """Two gloo ranks with unequal shards: ShardReducer (sum of the batch statistics, identity backward) + shard-
+    weighted mean term + GradBucket SUM reproduce the single-process loss and gradient of the whole batch."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = str(tmp_path / "exact")
+    mp.spawn(_exact_worker, args=(2, port, base), nprocs=2, join=True)
+    r0, r1 = torch.load(base + ".0"), torch.load(base + ".1")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.Sigmoid(), torch.nn.Linear(8, 4), torch.nn.Sigmoid())
+    g = torch.Generator().manual_seed(1)
+    x, labels = torch.rand(37, 6, generator=g), torch.randint(0, 5, (37,), generator=g)
+    loss = _toy_loss(net(x), labels, 5, None, 1.0)
+    loss.backward()
+    want = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    assert r0["n"] == want.numel()
+    torch.testing.assert_close(r0["flat"], r1["flat"], rtol=0, atol=0)          # replicas agree bit for bit
+    torch.testing.assert_close(r0["flat"], r0["first"], rtol=0, atol=0)         # buffer reuse is clean
+    torch.testing.assert_close(r0["flat"], want, rtol=1e-5, atol=1e-7)
+    # the matched term is replicated, the mean term is a share: loss_0 + loss_1 - matched = whole-batch loss
+    matched = loss - (net(x) ** 2).mean()
+    torch.testing.assert_close(r0["loss"] + r1["loss"] - matched.detach(), loss.detach(), rtol=1e-5, atol=1e-7)

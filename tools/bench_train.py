@@ -6,8 +6,10 @@ Not the headline bench (bench.py is).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/bench_train.py --gpus N
 
 With N ranks the rays of a step are sharded (strong scaling: --rays is the global batch), every rank runs forward and
-the hand-written backward on its shard, and ONE flat all-reduce (RCCL over xGMI; 5.57 MB) averages the gradients
-before Adam.  DMNERF_DIST_BACKEND=gloo rehearses the N > 1 path on one GPU."""
+the hand-written backward on its shard, the loss heads all-reduce their batch statistics (a few hundred bytes:
+class statistics of the instance matching, mask sums of the penalizer) so that the step optimises the loss of the WHOLE
+batch, and ONE in-place all-reduce (RCCL over xGMI; 5.57 MB) over the persistent flat gradient buffer sums the
+shard-weighted gradients before Adam.  DMNERF_DIST_BACKEND=gloo rehearses the N > 1 path on one GPU."""
 import argparse
 import json
 import os
@@ -61,14 +63,16 @@ rays = torch.stack([ro.reshape(-1, 3)[pick], rd.reshape(-1, 3)[pick]], 0)
 z = dm.z_val_sample(hi - lo, args.near, args.far, args.N_samples)
 opt = trainer.make_optimizer(coarse, fine)
 args.tolerance, args.deta_w = 0.05, 0.05
-ins = (lambda pred: dm.ins_criterion(pred, labels, 13)[0]) if ns.instance else None
-pen = (lambda raw, zz, depth: dm.ins_penalizer(raw, zz, depth, rays[1], args)) if ns.penalize else None
-reduce_grads = parallel.allreduce_gradients if world > 1 else None
+reducer = parallel.ShardReducer() if world > 1 else None
+bucket = parallel.GradBucket([coarse, fine])                # the weight-gradient kernels write straight into it
+ins = (lambda pred: dm.ins_criterion(pred, labels, 13, reduce=reducer)[0]) if ns.instance else None
+pen = (lambda raw, zz, depth: dm.ins_penalizer(raw, zz, depth, rays[1], args, reduce=reducer)) if ns.penalize else None
+reduce_grads = (lambda models: bucket.allreduce()) if world > 1 else None       # SUM of shard-weighted gradients
 
 
 def step(i):
     return trainer.train_step(i, rays, target, (pos, view, coarse, fine, args), z, opt, ins_loss=ins, penalizer=pen,
-                              allreduce=reduce_grads)
+                              allreduce=reduce_grads, shard=(hi - lo, ns.rays) if world > 1 else None)
 
 
 def barrier():

@@ -20,6 +20,8 @@ class _PenalizerFn(torch.autograd.Function):
         sums = torch.empty(4, dtype=torch.float64, device=raw.device)
         check(load().dmn_penalizer_fwd(ptr(raw), ptr(zz), stride, ptr(depth), ptr(rays_d), n, s, c, tolerance, deta_w,
                                        ptr(sums), current_stream()), "dmn_penalizer_fwd")
+        if reduce is not None:              # ray-sharded training: the two loss sums and the two mask counts of ALL shards
+            sums = reduce("penalizer_sums", sums)          # (penalizer.py:42-43,52 normalise by the batch's mask sums)
         ctx.save_for_backward(raw, zz, depth, rays_d, sums)
         ctx.meta = (stride, float(tolerance), float(deta_w))
         tiny = torch.full((), 1e-8, dtype=torch.float64, device=raw.device)

@@ -239,24 +239,41 @@ def _rays_off(got, want, tol=1e-4):
     return float((per_ray > tol * np.abs(want).max()).mean())
 
 
-def _check_path(out, g, prefix):
+# What the end-to-end comparisons observe on MI355X per arithmetic (tools/observed_parity.py prints them), and the caps
+# = 2x the observation.  "frac" = fraction of rays whose worst element leaves 1e-4 of full scale; the other entries are
+# worst deviations over all rays (relative to the expected tensor's max magnitude).  The fractions count 1..3 rays of
+# 128: a cap violation after a kernel change is adjudicated by test_flip_rate_against_oracle_on_2048_rays, which
+# measures the same thing on a sample large enough to be a rate.
+_PATH_CAPS = {   # observed G6 (det | rnd):   fp32 frac .0078 rgb 2.3e-4 depth 3.6e-4 ins 9.9e-6 | bf16x3 .0078 2.5e-4 3.6e-4 1.2e-5
+    #                                         fp16x3 frac .0234 rgb 3.9e-4 depth 5.1e-4 ins 1.9e-5; z_fine .0011-.0014, 1.4e-4
+    "fp32": dict(frac=0.0235, rgb=4.5e-4, depth=7.2e-4, ins=2.0e-5, z_frac=0.003, z_max=2.8e-4),
+    "fp16x3": dict(frac=0.047, rgb=7.9e-4, depth=1.0e-3, ins=3.8e-5, z_frac=0.003, z_max=2.4e-4),
+    "bf16x3": dict(frac=0.0235, rgb=5.0e-4, depth=7.2e-4, ins=2.5e-5, z_frac=0.003, z_max=2.4e-4),
+}
+_IMAGE_CAPS = {  # observed G8 (480 pixels): frac .0083 | .0104 | .0104, rgb 3.2e-4 | 5.8e-4 | 5.8e-4, ins 1.4e-5 | 2.8e-5 | 2.8e-5
+    "fp32": dict(frac=0.0167, rgb=6.4e-4, ins=2.8e-5), "fp16x3": dict(frac=0.021, rgb=1.2e-3, ins=5.6e-5),
+    "bf16x3": dict(frac=0.021, rgb=1.2e-3, ins=5.6e-5),
+}
+
+
+def _check_path(out, g, prefix, precision="fp32"):
     """End-to-end comparison of one dm_nerf call with the reference's output.
 
-    Everything up to the sampler must hold 1e-4 outright.  Behind the sampler the reference is not
-    1e-4-reproducible against ITSELF: run in fp64 on these very 128 rays it moves one ray's rgb_fine by
+    Everything up to the sampler must hold 1e-4 outright (observed: 7e-7; held to 2e-6).  Behind the sampler the
+    reference is not 1e-4-reproducible against ITSELF: run in fp64 on these very 128 rays it moves one ray's rgb_fine by
     2.3e-4 and depth_fine by 3.6e-4 of full scale, because `denom < 1e-5 -> 1` (helpers.py:150-151) makes
-    a resampled depth jump by a bin width on 1e-7 noise.  So the fine outputs are held to 1e-4 on >= 97 %
-    of the rays and to 2e-3 on all of them, and test_fine_stage_on_golden_depths holds the fine stage
-    itself (reference depths fed in) to 1e-4 outright."""
+    a resampled depth jump by a bin width on 1e-7 noise.  So the fine outputs are held to the per-arithmetic caps above,
+    and test_fine_stage_on_golden_depths holds the fine stage itself (reference depths fed in) to 1e-4 outright."""
+    cap = _PATH_CAPS[precision]
     for k in ("rgb_coarse", "ins_coarse", "depth_coarse", "z_vals_coarse"):
-        assert rel_err(H(out[k]), g[f"{prefix}_{k}"]) < 1e-4, k
-    for k in ("rgb_fine", "ins_fine", "depth_fine"):
+        assert rel_err(H(out[k]), g[f"{prefix}_{k}"]) < 2e-6, k
+    for k, name in (("rgb_fine", "rgb"), ("ins_fine", "ins"), ("depth_fine", "depth")):
         got, want = H(out[k]), g[f"{prefix}_{k}"]
-        assert _rays_off(got, want) <= 0.03, (k, _rays_off(got, want))
-        assert rel_err(got, want) < 2e-3, k
+        assert _rays_off(got, want) <= cap["frac"], (k, _rays_off(got, want))
+        assert rel_err(got, want) < cap[name], (k, rel_err(got, want))
     got, want = H(out["z_vals_fine"]), g[f"{prefix}_z_vals_fine"]
-    assert rel_err(got, want) < 2e-2                         # a flipped draw moves by one bin = 0.17 / 15
-    assert np.mean(np.abs(got - want) > 1e-4 * np.abs(want).max()) < 0.01
+    assert rel_err(got, want) < cap["z_max"]
+    assert np.mean(np.abs(got - want) > 1e-4 * np.abs(want).max()) < cap["z_frac"]
 
 
 def test_render_call_matches_reference_golden(golden):
@@ -307,19 +324,30 @@ def test_fine_stage_on_golden_depths_is_within_1e4(golden):
 
 
 # ---- G8 -------------------------------------------------------------------------------------
-def test_image_loop_with_ragged_tail_matches_reference_golden(golden):
+@pytest.mark.parametrize("precision", [None, "fp16x3", "bf16x3"])
+def test_image_loop_with_ragged_tail_matches_reference_golden(golden, precision):
+    """render_test on a 20x24 image in chunks of 100 (ragged tail of 80).  precision None = the image loop's default,
+    which must be the reference's arithmetic (exact fp32 products)."""
     g = golden("g8_image.npz")
     Hh, W = 20, 24
     pos, view, coarse, fine, args = nets(13, 0, 1)
     args.N_test = 100
+    if precision is not None:
+        args.precision = precision
     rgbs, inss, psnrs = dm.render_test(pos, view, coarse, fine, [cases.study_c2w()],
                                        [Hh, W, cases.study_intrinsics(Hh, W)], args, gt_imgs=[g["rgb"]])
     assert rgbs[0].shape == (Hh, W, 3) and inss[0].shape == (Hh, W, 13)
-    for got, want in ((H(rgbs[0]).reshape(-1, 3), g["rgb"].reshape(-1, 3)),
-                      (H(inss[0]).reshape(-1, 13), g["ins"].reshape(-1, 13))):
-        assert _rays_off(got, want) <= 0.03                      # sampler noise floor, see _check_path
-        assert rel_err(got, want) < 2e-3
-    assert psnrs[0] > 80.0                                     # PSNR of the HIP render against the reference's
+    cap = _IMAGE_CAPS[precision or "fp32"]
+    for got, want, name in ((H(rgbs[0]).reshape(-1, 3), g["rgb"].reshape(-1, 3), "rgb"),
+                            (H(inss[0]).reshape(-1, 13), g["ins"].reshape(-1, 13), "ins")):
+        assert _rays_off(got, want) <= (cap["frac"] if name == "rgb" else 0.0), (name, _rays_off(got, want))
+        assert rel_err(got, want) < cap[name], (name, rel_err(got, want))
+    assert psnrs[0] > 90.0                                     # PSNR of the HIP render against the reference's (94-99 dB)
+    if precision is None:                                      # the default is exact fp32, bit for bit
+        args.precision = "fp32"
+        again, _, _ = dm.render_test(pos, view, coarse, fine, [cases.study_c2w()], [Hh, W, cases.study_intrinsics(Hh, W)],
+                                     args)
+        np.testing.assert_array_equal(H(again[0]), H(rgbs[0]))
 
 
 # ---- BASELINE sizes: size-independent properties ------------------------------------------------
@@ -352,10 +380,11 @@ def test_full_size_chunk_properties():
     with torch.no_grad():
         want = oracle.render_rays(rays[:, pick].cpu(), oracle.make_params(13, 0), oracle.make_params(13, 1),
                                   oracle.coarse_depths(48, args.near, args.far, 64))
-    for k in ("rgb_fine", "ins_fine", "depth_fine"):
-        assert _rays_off(H(full[k])[pick], want[k].numpy()) <= 0.05, k
-        assert rel_err(H(full[k])[pick], want[k].numpy()) < 2e-3, k
-    assert rel_err(H(full["rgb_coarse"])[pick], want["rgb_coarse"].numpy()) < 1e-4
+    # observed on these 48 rays (fp32): none beyond 1e-4; rgb 4.0e-5, ins 2.2e-6, depth 9.2e-5 worst
+    for k, cap in (("rgb_fine", 8e-5), ("ins_fine", 5e-6), ("depth_fine", 1.9e-4)):
+        assert _rays_off(H(full[k])[pick], want[k].numpy()) <= 0.021, k
+        assert rel_err(H(full[k])[pick], want[k].numpy()) < cap, k
+    assert rel_err(H(full["rgb_coarse"])[pick], want["rgb_coarse"].numpy()) < 2e-6
 
 
 def test_replica_shape_config():
@@ -385,7 +414,8 @@ def test_replica_shape_config():
 # Observed on MI355X (this test's print, and bench.py's `deviation_vs_cpu_oracle` on 16384 rays): the fraction of rays
 # whose fine outputs leave 1e-4 is the same in all three arithmetics -- it is the rate at which the reference's sampler
 # flips on 1e-7 noise, not a property of the field kernel's precision.  Caps = 2x the observed rate.
-_FLIP_CAPS = {"fp32": (0.016, 0.021), "fp16x3": (0.016, 0.021), "bf16x3": (0.017, 0.022)}    # (rgb_fine, depth_fine)
+# observed (2048 random pixels of the 800x800 image): fp32 0.0117 / 0.0132, fp16x3 0.0093 / 0.0117, bf16x3 0.0112 / 0.0142
+_FLIP_CAPS = {"fp32": (0.0235, 0.0265), "fp16x3": (0.0190, 0.0235), "bf16x3": (0.0225, 0.0285)}    # (rgb_fine, depth_fine)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "fp16x3", "bf16x3"])
@@ -411,7 +441,7 @@ def test_flip_rate_against_oracle_on_2048_rays(precision):
     cap_rgb, cap_depth = _FLIP_CAPS[precision]
     assert seen["rgb_fine"][0] <= cap_rgb and seen["depth_fine"][0] <= cap_depth, seen
     assert seen["ins_fine"][0] <= 0.002, seen                           # the instance map is smooth in the depths
-    assert seen["rgb_fine"][1] < 4e-3 and seen["depth_fine"][1] < 6e-3  # one flipped draw = one bin (0.175 of 15)
+    assert seen["rgb_fine"][1] < 2.1e-3 and seen["depth_fine"][1] < 3.1e-3   # 2x the observed worst (1.05e-3, 1.54e-3)
 
 
 # ---- BASELINE config 5: ScanNet full-resolution render_path with the loader's crop mask, image-sharded ----------
@@ -451,8 +481,9 @@ def test_scannet_full_resolution_render_with_crop_mask():
     got_rgb, got_ins = H(full_rgb).reshape(-1, 3)[pick], H(full_ins).reshape(-1, ins_num)[pick]
     print("scannet sample: rays off", _rays_off(got_rgb, want["rgb_fine"].numpy()), _rays_off(got_ins, want["ins_fine"].numpy()),
           "worst", rel_err(got_rgb, want["rgb_fine"].numpy()), rel_err(got_ins, want["ins_fine"].numpy()))
-    assert _rays_off(got_rgb, want["rgb_fine"].numpy()) <= 0.05 and rel_err(got_rgb, want["rgb_fine"].numpy()) < 2e-3
-    assert _rays_off(got_ins, want["ins_fine"].numpy()) <= 0.05 and rel_err(got_ins, want["ins_fine"].numpy()) < 2e-3
+    # observed: 2 of 64 rays beyond 1e-4 in rgb (4.1e-4 worst), none in ins (2.1e-5 worst)
+    assert _rays_off(got_rgb, want["rgb_fine"].numpy()) <= 0.0625 and rel_err(got_rgb, want["rgb_fine"].numpy()) < 8.5e-4
+    assert _rays_off(got_ins, want["ins_fine"].numpy()) <= 0.02 and rel_err(got_ins, want["ins_fine"].numpy()) < 1e-4
 
 
 def test_pose_sharded_render_path_over_eight_poses():
@@ -507,7 +538,7 @@ def test_split_precision_on_rays_and_whole_call(golden, precision):
     z = dm.z_val_sample(n, cases.NEAR, cases.FAR, cases.N_SAMPLES)
     with torch.no_grad():
         out = dm.dm_nerf(rays, pos, view, coarse, fine, z, args)
-    _check_path(out, g, "det")
+    _check_path(out, g, "det", precision)
     assert rel_err(H(out["raw_coarse"][:8]), g["det_raw_coarse_head"]) < 1e-4
     # fine stage on the reference's depths: 1e-4 outright
     z_fine = G(g["det_z_vals_fine"])
@@ -614,6 +645,9 @@ def test_training_gradients_match_reference_golden(golden, precision):
         for name, p in net.named_parameters():
             got = H(p.grad)[cases.grad_digest_slices(name, p.shape)]
             err = rel_err(got, g[f"{tag}.{name}"])
+            l2 = float(np.linalg.norm((got - g[f"{tag}.{name}"]).astype(np.float64))
+                       / max(np.linalg.norm(g[f"{tag}.{name}"].astype(np.float64)), 1e-30))
+            print(f"   {precision} {tag}.{name}: max-rel {err:.2e}  l2-rel {l2:.2e}")
             worst = max(worst, err)
             # Coarse-network gradients do not see the sampler: 1e-4.  Fine-network gradients are evaluated at the
             # resampled depths, and the reference disagrees with ITSELF there by 3.5e-2 (its fp64 run against
@@ -731,7 +765,10 @@ def test_field_backward_kernels_match_library_gemm_backward(ins_num, n, s, fwd, 
     # A ReLU whose pre-activation is within rounding of zero may open in one forward and close in the other; that
     # is a different function, not an error.  Points with such a unit get no gradient in this comparison.
     # (the bf16x3 forward differs from torch's by ~1e-5 of the activation scale, the exact one by ~1e-6)
-    fragile = H(_min_abs_preactivation(net, G(o), G(d), G(z))) < (1e-5 if fwd == "fp32" else 1e-4)
+    low = H(_min_abs_preactivation(net, G(o), G(d), G(z)))
+    fragile = low < (1e-5 if fwd == "fp32" else 1e-4)
+    print(f"fragile points: {fragile.mean():.3f} (|pre-activation| < 1e-5: {(low < 1e-5).mean():.3f}, < 3e-5: "
+          f"{(low < 3e-5).mean():.3f}, < 1e-4: {(low < 1e-4).mean():.3f})")
     assert fragile.mean() < (0.25 if fwd == "fp32" else 0.9)
     g_raw[fragile] = 0.0
     grads = {}
@@ -1035,9 +1072,10 @@ def test_manipulator_render_and_nerf_match_the_reference(golden):
 def test_manipulator_two_pass_rerender_matches_the_reference(golden):
     """manipulator() (networks/manipulator.py:137-205) with the reference's recorded torch.rand draws: two moved
     objects, labels 1 and 4.  Point labels of both exchanges, the merged depths of both passes and the four returned
-    maps.  Like dm_nerf's fine outputs the result sits behind two stochastic resamplings and, here, behind argmax
-    label decisions, so a ray can leave 1e-4 when one of its points changes label on rounding noise: the labels are
-    held to >= 99.5 % agreement, the maps to 1e-4 on the rays whose labels all agree."""
+    maps.  Like dm_nerf's fine outputs the result sits behind stochastic resamplings and, here, behind argmax label
+    decisions, so a ray may leave the bound when one of its points changes label on rounding noise: the labels are held
+    to >= 99.9 % agreement (observed: all equal), the maps to 1e-5 on the rays whose labels all agree (observed: all
+    rays, 3e-6)."""
     g = golden("g12_manipulator.npz")
     o, d, tars, draws = cases.manipulator_case()
     pos, view, coarse, fine, args = nets(13, 0, 1)
@@ -1083,11 +1121,12 @@ def test_manipulator_two_pass_rerender_matches_the_reference(golden):
         errs[key] = (float(diff[ray_ok].max()) if ray_ok.any() else 0.0, float(diff.max()), float((diff > 1e-4).mean()))
     print(f"manipulator: depths off {off1:.4f} / {off2:.4f}, pass-2 labels agree {agree}, rays with all labels equal "
           f"{ray_ok.mean():.3f}, (err on those, err on all, rays > 1e-4): {errs}")
-    assert off1 <= 0.01 and off2 <= 0.01
-    assert min(agree) >= 0.995
-    assert ray_ok.mean() >= 0.75
+    # observed on MI355X: every depth within 1e-4, every label equal, maps within 3.1e-6 / 1.8e-6 / 1.7e-7 / 8.4e-7
+    assert off1 <= 0.002 and off2 <= 0.002
+    assert min(agree) >= 0.999
+    assert ray_ok.mean() >= 0.95
     for key, (e_ok, e_all, frac) in errs.items():
-        assert e_ok < 1e-4, (key, e_ok)
+        assert e_ok < 1e-5, (key, e_ok)
     assert rel_err(H(tar_rgb), g["mp_tar_rgb"]) < 1e-4          # coarse pass of the last object: no resampling involved
     # own draws: deterministic under a fixed seed
     margs.u_draws = None

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/dmnerf_hip.h"
+#include "composite_common.h"
 #include "field_layout.h"
 #include "trig.h"
 
@@ -15,37 +16,6 @@ namespace {
 constexpr int kWavesPerBlock = 4;
 
 inline int launch_status() { return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH; }
-
-// Sum over the 64 lanes, result in every lane.  Within a 16-lane row by DPP (quad permutes, then row
-// rotates by 4 and 8: register-to-register, no LDS crossbar round trips as ds_bpermute-based shuffles
-// have), then the four row totals through v_readlane.  Latency of the dependent chain matters here: the
-// compositing kernel reduces one channel after another.
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
-}
-__device__ __forceinline__ float wave_sum(float v) {
-  v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
-  v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
-  v += dpp_mov<0x124>(v);   // row_ror:4
-  v += dpp_mov<0x128>(v);   // row_ror:8  -> every lane holds its row's total
-  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
-  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
-  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
-  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
-  return (r0 + r1) + (r2 + r3);
-}
-
-// inclusive scan (sum or product) across the 64 lanes, in fp64
-template <bool PRODUCT>
-__device__ __forceinline__ double wave_scan(double v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const double t = __shfl_up(v, d);
-    if (lane >= d) v = PRODUCT ? v * t : v + t;
-  }
-  return v;
-}
 
 // ------------------------------------------------------------------------------------------
 // blob gather
@@ -145,14 +115,12 @@ __global__ void encode_kernel(const float* __restrict__ x, long n_points, int n_
 
 // ------------------------------------------------------------------------------------------
 // alpha compositing: render_train (networks/render.py:6-28), manipulator_render
-// (networks/manipulator.py:86-105)
+// (networks/manipulator.py:86-105).  One wavefront per ray; the per-slab arithmetic lives in
+// composite_common.h (shared with the fused field + compositing kernel, which must give the same bits).
 //
-// One wavefront per ray.  The ray's raw block is walked in 64-sample slabs: a slab (64 x C
-// contiguous floats) is copied global -> LDS with wave-wide contiguous loads (every HBM byte is
-// fetched once, fully coalesced), lane i then owns sample i of the slab.  Transmittance is an
-// exclusive product scan across the wavefront in fp64 (PyTorch's CPU cumprod accumulates in
-// double, ATen acc_type<float>), carried from slab to slab.  Channel sums are wave reductions;
-// lane (c mod 64) keeps the running total of channel c.
+// composite_kernel (rows of up to kWideChannels floats): the ray's raw block is walked in 64-sample slabs, a slab
+// (64 x C contiguous floats) is copied global -> LDS with wave-wide contiguous loads (every HBM byte is fetched once,
+// fully coalesced), lane i then owns sample i of the slab.
 // (A whole-ray variant -- one wave per workgroup, all slabs loaded up front, one reduction per channel per
 // ray -- measured 12 % slower on the same device at the render loop's 4096-ray launches: 2.16 vs 2.47 TB/s.)
 // ------------------------------------------------------------------------------------------
@@ -169,8 +137,6 @@ struct CompositeArgs {
   float* ins;
 };
 
-constexpr int kWideChannels = 32;   // wider raw rows are composited by composite_wide_kernel (no LDS slab)
-
 __global__ __launch_bounds__(64 * kWavesPerBlock) void composite_kernel(CompositeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63;
@@ -180,14 +146,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void composite_kernel(Composit
   const long n = (long)blockIdx.x * kWavesPerBlock + wave;
   const bool ray_ok = n < a.n_rays;
   const long nc = ray_ok ? n : a.n_rays - 1;
-
-  const float dx = a.rays_d[3 * nc + 0], dy = a.rays_d[3 * nc + 1], dz = a.rays_d[3 * nc + 2];
-  const float norm = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+  const float norm = ray_norm(a.rays_d + 3 * nc);
   const float* zr = a.z + nc * a.zs;
   const float* rawr = a.raw + nc * (long)S * C;
 
-  float tot[3] = {0.f, 0.f, 0.f};   // lane l: running sums of channels l, 64+l, 128+l
-  double carry = 1.0;               // transmittance entering the slab
+  RayComposite st;
   const int n_slabs = (S + 63) / 64;
   for (int b = 0; b < n_slabs; ++b) {
     const int s0 = b * 64;
@@ -204,207 +167,40 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void composite_kernel(Composit
       for (int i = lane; i < nfl; i += 64) slab[i] = src[i];
     }
     __syncthreads();
-
-    const int s = s0 + lane;
-    const bool ok = lane < cnt;
-    const float zc = ok ? zr[s] : 0.f;
-    // dists = cat([z[1:] - z[:-1], 1e10]) * ||d||   (render.py:9-12)
-    float delta = 1e10f;
-    if (ok && s + 1 < S) delta = __fsub_rn(zr[s + 1], zc);
-    delta = __fmul_rn(delta, norm);
-    const float sigma = ok ? slab[lane * C + 3] : 0.f;
-    // alpha = 1 - exp(-relu(sigma) * dists)   (render.py:7,16)
-    const float alpha = ok ? __fsub_rn(1.f, expf(-__fmul_rn(fmaxf(sigma, 0.f), delta))) : 0.f;
-    // T = exclusive cumprod(1 - alpha + 1e-10)   (render.py:18)
-    const double f = ok ? (double)__fadd_rn(__fsub_rn(1.f, alpha), 1e-10f) : 1.0;
-    const double incl = wave_scan<true>(f, lane);
-    double excl = __shfl_up(incl, 1);
-    if (lane == 0) excl = 1.0;
-    const float T = (float)(carry * excl);
-    carry = carry * __shfl(incl, 63);
-    const float w = ok ? __fmul_rn(alpha, T) : 0.f;
-    if (ok && ray_ok && a.weights) a.weights[n * S + s] = w;
-
-    // channel sums: rgb through sigmoid (render.py:14,19), channel 3 carries depth (render.py:20),
-    // instance logits raw (render.py:24)
-    // lane = sample, one wave reduction per channel (rows of up to kWideChannels channels; wider rows go to
-    // composite_wide_kernel)
-#pragma unroll
-    for (int cb = 0; cb < 3; ++cb) {
-      const int cend = min(C - cb * 64, 64);
-      for (int cc = 0; cc < cend; ++cc) {
-        const int c = cb * 64 + cc;
-        float v = ok ? slab[lane * C + c] : 0.f;
-        if (c < 3) v = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-v)));
-        if (c == 3) v = zc;
-        v = wave_sum(__fmul_rn(w, v));
-        if (lane == cc) tot[cb] += v;
-      }
-    }
+    const float w = composite_slab<false>(st, slab, zr, s0, cnt, S, C, norm, lane);
+    if (lane < cnt && ray_ok && a.weights) a.weights[n * S + s0 + lane] = w;
   }
-
   if (!ray_ok) return;
-  const int K = a.keep_last ? C - 4 : C - 5;
-#pragma unroll
-  for (int cb = 0; cb < 3; ++cb) {
-    const int c = cb * 64 + lane;
-    if (c >= C) continue;
-    if (c < 3) {
-      if (a.rgb) a.rgb[3 * n + c] = tot[cb];
-    } else if (c == 3) {
-      if (a.depth) a.depth[n] = tot[cb];
-    } else if (c - 4 < K) {
-      // ins_map = sigmoid(sum w * logits)   (render.py:24-26)
-      if (a.ins) a.ins[n * K + (c - 4)] = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-tot[cb])));
-    }
-  }
+  composite_outputs(st, n, C, a.keep_last, lane, a.rgb, a.depth, a.ins);
 }
 
 // Compositing for wide rows (C > kWideChannels; Replica / ScanNet carry ~100 channels): no LDS slab.  Lane = sample
 // reads only the density column for the transmittance scan; then the lanes turn to channels (lane l owns channels
 // l, 64 + l, 128 + l) and walk the slab's samples with rows read straight from global memory -- every row is one
 // contiguous wave access, each raw byte comes from HBM once (the density column's lines are met again in L2), and
-// without a 25 KB slab per ray the occupancy is no longer set by LDS.  Same arithmetic as composite_kernel's walk.
+// without a 25 KB slab per ray the occupancy is no longer set by LDS.
 __global__ __launch_bounds__(64 * kWavesPerBlock) void composite_wide_kernel(CompositeArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int C = a.C, S = a.S;
   const long n = (long)blockIdx.x * kWavesPerBlock + wave;
   if (n >= a.n_rays) return;                        // no block-level synchronisation in this kernel
-
-  const float dx = a.rays_d[3 * n + 0], dy = a.rays_d[3 * n + 1], dz = a.rays_d[3 * n + 2];
-  const float norm = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+  const float norm = ray_norm(a.rays_d + 3 * n);
   const float* zr = a.z + n * a.zs;
   const float* rawr = a.raw + n * (long)S * C;
-
-  float tot[3] = {0.f, 0.f, 0.f};
-  double carry = 1.0;
+  RayComposite st;
   for (int s0 = 0; s0 < S; s0 += 64) {
     const int cnt = min(64, S - s0);
-    const int s = s0 + lane;
-    const bool ok = lane < cnt;
-    const float zc = ok ? zr[s] : 0.f;
-    float delta = 1e10f;
-    if (ok && s + 1 < S) delta = __fsub_rn(zr[s + 1], zc);
-    delta = __fmul_rn(delta, norm);
-    const float sigma = ok ? rawr[(long)s * C + 3] : 0.f;
-    const float alpha = ok ? __fsub_rn(1.f, expf(-__fmul_rn(fmaxf(sigma, 0.f), delta))) : 0.f;
-    const double f = ok ? (double)__fadd_rn(__fsub_rn(1.f, alpha), 1e-10f) : 1.0;
-    const double incl = wave_scan<true>(f, lane);
-    double excl = __shfl_up(incl, 1);
-    if (lane == 0) excl = 1.0;
-    const float T = (float)(carry * excl);
-    carry = carry * __shfl(incl, 63);
-    const float w = ok ? __fmul_rn(alpha, T) : 0.f;
-    if (ok && a.weights) a.weights[n * S + s] = w;
-
-    const float* row = rawr + (long)s0 * C;
-#pragma unroll 8
-    for (int sidx = 0; sidx < cnt; ++sidx, row += C) {
-      const float ws = __shfl(w, sidx), zs = __shfl(zc, sidx);
-#pragma unroll
-      for (int cb = 0; cb < 3; ++cb) {
-        const int c = cb * 64 + lane;
-        if (c < C) {
-          float v = row[c];
-          if (cb == 0) {
-            if (lane < 3) v = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-v)));
-            if (lane == 3) v = zs;
-          }
-          tot[cb] = fmaf(ws, v, tot[cb]);
-        }
-      }
-    }
+    const float w = composite_slab<true>(st, rawr + (long)s0 * C, zr, s0, cnt, S, C, norm, lane);
+    if (lane < cnt && a.weights) a.weights[n * S + s0 + lane] = w;
   }
-
-  const int K = a.keep_last ? C - 4 : C - 5;
-#pragma unroll
-  for (int cb = 0; cb < 3; ++cb) {
-    const int c = cb * 64 + lane;
-    if (c >= C) continue;
-    if (c < 3) {
-      if (a.rgb) a.rgb[3 * n + c] = tot[cb];
-    } else if (c == 3) {
-      if (a.depth) a.depth[n] = tot[cb];
-    } else if (c - 4 < K) {
-      if (a.ins) a.ins[n * K + (c - 4)] = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-tot[cb])));
-    }
-  }
+  composite_outputs(st, n, C, a.keep_last, lane, a.rgb, a.depth, a.ins);
 }
 
 // ------------------------------------------------------------------------------------------
 // sample_pdf (networks/helpers.py:123-155) and the resample + merge step of dm_nerf
 // (networks/render.py:66-70).  One wavefront per ray, pdf/cdf and candidates in LDS.
 // ------------------------------------------------------------------------------------------
-
-// cdf[0..B-1] from B-1 weights: w += 1e-5; pdf = w / sum(w); cdf = [0, cumsum(pdf)]
-// (helpers.py:125-128).  The running sum is fp64, rounded per element (ATen CPU cumsum).
-__device__ void build_cdf(const float* __restrict__ w, int nw, float* cdf, int lane) {
-  float part = 0.f;
-  for (int j = lane; j < nw; j += 64) part += __fadd_rn(w[j], 1e-5f);
-  const float total = wave_sum(part);
-  double carry = 0.0;
-  if (lane == 0) cdf[0] = 0.f;
-  for (int j0 = 0; j0 < nw; j0 += 64) {
-    const int j = j0 + lane;
-    const double p = j < nw ? (double)__fdiv_rn(__fadd_rn(w[j], 1e-5f), total) : 0.0;
-    const double incl = wave_scan<false>(p, lane) + carry;
-    if (j < nw) cdf[j + 1] = (float)incl;
-    carry = __shfl(incl, 63);
-  }
-}
-
-// one draw: searchsorted(right) -> gather -> lerp (helpers.py:139-153)
-__device__ __forceinline__ float invert_cdf(const float* cdf, const float* bins, int B, float u) {
-  int lo = 0, hi = B;                      // first index with cdf[idx] > u
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
-  }
-  const int below = max(lo - 1, 0), above = min(lo, B - 1);
-  const float cb = cdf[below], ca = cdf[above];
-  float den = __fsub_rn(ca, cb);
-  if (den < 1e-5f) den = 1.f;
-  const float t = __fdiv_rn(__fsub_rn(u, cb), den);
-  const float bb = bins[below], ba = bins[above];
-  return __fadd_rn(bb, __fmul_rn(t, __fsub_rn(ba, bb)));
-}
-
-// torch.linspace(0, 1, n) as ATen's CPU kernel evaluates it in fp32: step = 1/(n-1); lower half
-// start + step*k, upper half end - step*(n-1-k) with the multiply-subtract fused (bit-identical to
-// torch.linspace for the sizes tested: 40, 64, 128).
-__device__ __forceinline__ float linspace01(int k, int n) {
-  if (n == 1) return 0.f;
-  const float step = __fdiv_rn(1.f, (float)(n - 1));
-  return k < n / 2 ? __fmul_rn(step, (float)k) : fmaf(-step, (float)(n - 1 - k), 1.f);
-}
-
-// ascending rank sort of L values held in LDS `vals` into global `out` (ties by index).  NaNs order after every
-// number (as torch.sort does), again by index, so the ranks stay a permutation and every output slot is written.
-__device__ void rank_sort_to(const float* vals, int L, float* __restrict__ out, int lane) {
-  for (int e0 = 0; e0 < L; e0 += 256) {   // four candidates per lane per pass
-    float v[4];
-    int id[4], rank[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      id[q] = e0 + q * 64 + lane;
-      v[q] = id[q] < L ? vals[id[q]] : 0.f;
-      rank[q] = 0;
-    }
-    for (int f = 0; f < L; ++f) {
-      const float x = vals[f];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const bool xn = x != x, vn = v[q] != v[q];
-        const bool before = x < v[q] || (vn && !xn), same = x == v[q] || (xn && vn);
-        rank[q] += (before || (same && f < id[q])) ? 1 : 0;
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (id[q] < L) out[rank[q]] = v[q];
-  }
-}
 
 struct SampleArgs {
   const float* bins; long bins_stride;
@@ -450,29 +246,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void resample_merge_kernel(Res
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long n = (long)blockIdx.x * kWavesPerBlock + wave;
   if (n >= a.n_rays) return;
-  const int S = a.S, B = S - 1, L = S + a.n_new;
-  // per-wave LDS: all[L] (coarse then new depths), cdf[B], bins[B]
+  const int S = a.S, L = S + a.n_new;
+  // per-wave LDS: all[L] (coarse then new depths), cdf[S], bins[S]
   float* all = smem + (long)wave * (L + 2 * S);
-  float* cdf = all + L;
-  float* bins = cdf + S;
-  const float* zr = a.z + n * a.zs;
-  for (int j = lane; j < S; j += 64) all[j] = zr[j];
-  if (a.n_new > 0) {
-    // z_vals_mid = .5 * (z[1:] + z[:-1])   (render.py:66)
-    for (int j = lane; j < B; j += 64) bins[j] = __fmul_rn(0.5f, __fadd_rn(zr[j + 1], zr[j]));
-    // weights[..., 1:-1]   (render.py:67)
-    build_cdf(a.weights + n * S + 1, S - 2, cdf, lane);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (int k = lane; k < a.n_new; k += 64) {
-      const float u = a.u ? a.u[n * a.u_stride + k] : linspace01(k, a.n_new);
-      all[S + k] = invert_cdf(cdf, bins, B, u);
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  // z_vals_fine = sort(cat([z_coarse, z_samples]))   (render.py:70)
-  rank_sort_to(all, L, a.z_fine + n * L, lane);
+  resample_merge_ray(a.z + n * a.zs, a.weights + n * S, a.u ? a.u + n * a.u_stride : nullptr, S, a.n_new, all, all + L,
+                     all + L + S, a.z_fine + n * L, lane);
 }
 
 struct MergeArgs {

@@ -235,6 +235,10 @@ def main():
     ap.add_argument("--workload", default="study", choices=["study", "replica"],
                     help="study = BASELINE config 2 (the headline: DM-SR 'study' 800x800, ins_num 13); replica = config 3 "
                          "shape (room_0: 640x480, ins_num 93, near 0 / far 6.5) for a side measurement")
+    ap.add_argument("--fused", default="auto", choices=["auto", "on", "off"],
+                    help="split-precision modes: field + compositing (+ resampling) fused in one kernel (`raw` never in "
+                         "HBM; same bits) or the chained kernels; auto = render_image's rule (fused for rows wider than 32 "
+                         "channels)")
     ap.add_argument("--no-train-leg", action="store_true",
                     help="skip the extra training-step measurement after the timed region (N = 1 only)")
     ns = ap.parse_args()
@@ -275,7 +279,7 @@ def main():
 
     def make_step(precision, **kw):
         from types import SimpleNamespace
-        a = SimpleNamespace(**{**vars(args), "precision": precision})
+        a = SimpleNamespace(**{**vars(args), "precision": precision, "fused": {"auto": None, "on": True, "off": False}[ns.fused]})
         return lambda: dm.render_image(pos, view, coarse, fine, pose, hwk, a, chunk=ns.chunk, **kw)
 
     def barrier():
@@ -302,7 +306,7 @@ def main():
     # composite launches alternate S=64 and S=192 with the same ray count; bytes by sample total
     comp_bytes = (pts_c // (N_SAMPLES + N_SAMPLES + N_IMPORTANCE)) * (
         composite_bytes(1, N_SAMPLES, c_ch) + composite_bytes(1, N_SAMPLES + N_IMPORTANCE, c_ch))
-    comp_gbs = comp_bytes / t_c / 1e9
+    comp_gbs = comp_bytes / t_c / 1e9 if t_c > 0 else 0.0      # fused modes have no stand-alone compositing launches
     dtype_names = {"fp32": "f32", "fp16x3": "f16x3 (hi/lo split, f32 accumulate)",
                    "bf16x3": "bf16x3 (hi/lo split, f32 accumulate)"}
 

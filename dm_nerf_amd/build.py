@@ -17,9 +17,9 @@ from concurrent.futures import ThreadPoolExecutor
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libdmnerf_hip.so")
 OBJ = os.path.join(CSRC, "build")
-SOURCES = ["field_fwd.hip", "field_fwd_x3.hip", "field_bwd.hip", "field_bwd_x3.hip", "render_ops.hip",
+SOURCES = ["field_fwd.hip", "field_fwd_x3.hip", "field_fused_x3.hip", "field_bwd.hip", "field_bwd_x3.hip", "render_ops.hip",
            "composite_bwd.hip", "penalizer.hip", "ins_stats.hip", "exchange.hip", "field_pack.cpp", "render_chain.cpp"]
-HEADERS = ["field_layout.h", "field_common.h", "field_stream.h", "field_x3.h", "trig.h",
+HEADERS = ["field_layout.h", "field_common.h", "field_stream.h", "field_x3.h", "field_x3_net.h", "composite_common.h", "trig.h",
            os.path.join("..", "..", "include", "dmnerf_hip.h")]
 # -ffp-contract=off: the path reproduces separately rounded fp32 multiplies and adds of the
 # reference (e.g. pts = o + d*z feeds a 2^9 frequency band); fused multiply-adds are explicit.

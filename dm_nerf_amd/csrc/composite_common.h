@@ -59,16 +59,20 @@ struct RayComposite {
 //   dists = cat([z[1:] - z[:-1], 1e10]) * ||d||; alpha = 1 - exp(-relu(sigma) * dists)          (render.py:7,9-12,16)
 //   T = exclusive cumprod(1 - alpha + 1e-10), in fp64 as ATen's CPU cumprod (acc_type<float>)    (render.py:18)
 //   channel sums: rgb through sigmoid (:14,19), channel 3 carries depth (:20), instance logits raw (:24)
+// `maps` = false skips the channel sums (st.tot stays 0).
 // WIDE = false: lane = sample, one wave reduction per channel.  WIDE = true: the lanes turn to channels (lane l owns
 // channels l, 64 + l, 128 + l) and walk the slab's rows, one contiguous wave access per row.
 template <bool WIDE>
-__device__ __forceinline__ float composite_slab(RayComposite& st, const float* rows, const float* zr, int s0, int cnt,
-                                                int S, int C, float norm, int lane) {
+__device__ __forceinline__ float composite_slab(RayComposite& st, const float* rows, float zc, float znext, int s0,
+                                                int cnt, int S, int C, float norm, int lane, bool maps = true,
+                                                int c_lo = 0, int c_hi = 1 << 30) {
+  // zc = z[s0 + lane], znext = z[s0 + lane + 1] (unused for the ray's last sample): loaded by the caller, which may
+  // have them in flight long before (the fused kernel asks for them ahead of the network evaluation)
   const int s = s0 + lane;
   const bool ok = lane < cnt;
-  const float zc = ok ? zr[s] : 0.f;
+  if (!ok) zc = 0.f;
   float delta = 1e10f;
-  if (ok && s + 1 < S) delta = __fsub_rn(zr[s + 1], zc);
+  if (ok && s + 1 < S) delta = __fsub_rn(znext, zc);
   delta = __fmul_rn(delta, norm);
   const float sigma = ok ? rows[(long)lane * C + 3] : 0.f;
   const float alpha = ok ? __fsub_rn(1.f, expf(-__fmul_rn(fmaxf(sigma, 0.f), delta))) : 0.f;
@@ -79,12 +83,15 @@ __device__ __forceinline__ float composite_slab(RayComposite& st, const float* r
   const float T = (float)(st.carry * excl);
   st.carry = st.carry * __shfl(incl, 63);
   const float w = ok ? __fmul_rn(alpha, T) : 0.f;
+  if (!maps) return w;              // only the weights are wanted (density-only coarse pass of an image loop)
 
   if (!WIDE) {
+    // channels c_lo .. c_hi-1 only (the fused kernel splits a ray's channels over two waves; every channel's sum is
+    // its own chain, so the split changes no bit)
 #pragma unroll
     for (int cb = 0; cb < 3; ++cb) {
-      const int cend = min(C - cb * 64, 64);
-      for (int cc = 0; cc < cend; ++cc) {
+      const int cend = min(min(C, c_hi) - cb * 64, 64);
+      for (int cc = max(c_lo - cb * 64, 0); cc < cend; ++cc) {
         const int c = cb * 64 + cc;
         float v = ok ? rows[(long)lane * C + c] : 0.f;
         if (c < 3) v = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-v)));
@@ -115,15 +122,26 @@ __device__ __forceinline__ float composite_slab(RayComposite& st, const float* r
   return w;
 }
 
+// the same with the two depths read here (stand-alone kernels: many waves per CU hide the latency)
+template <bool WIDE>
+__device__ __forceinline__ float composite_slab(RayComposite& st, const float* rows, const float* zr, int s0, int cnt,
+                                                int S, int C, float norm, int lane, bool maps = true) {
+  const int s = s0 + lane;
+  const float zc = lane < cnt ? zr[s] : 0.f;
+  const float znext = (lane < cnt && s + 1 < S) ? zr[s + 1] : 0.f;
+  return composite_slab<WIDE>(st, rows, zc, znext, s0, cnt, S, C, norm, lane, maps);
+}
+
 // the maps of ray n: rgb[3], depth, ins_map = sigmoid(sum w * logits)[: K]   (render.py:24-26; K keeps or drops the
 // last, "air", channel)
 __device__ __forceinline__ void composite_outputs(const RayComposite& st, long n, int C, int keep_last, int lane,
-                                                  float* rgb, float* depth, float* ins) {
+                                                  float* rgb, float* depth, float* ins, int c_lo = 0,
+                                                  int c_hi = 1 << 30) {
   const int K = keep_last ? C - 4 : C - 5;
 #pragma unroll
   for (int cb = 0; cb < 3; ++cb) {
     const int c = cb * 64 + lane;
-    if (c >= C) continue;
+    if (c >= C || c < c_lo || c >= c_hi) continue;
     if (c < 3) {
       if (rgb) rgb[3 * n + c] = st.tot[cb];
     } else if (c == 3) {
@@ -136,7 +154,7 @@ __device__ __forceinline__ void composite_outputs(const RayComposite& st, long n
 
 // cdf[0..B-1] from B-1 weights: w += 1e-5; pdf = w / sum(w); cdf = [0, cumsum(pdf)]
 // (helpers.py:125-128).  The running sum is fp64, rounded per element (ATen CPU cumsum).
-__device__ void build_cdf(const float* __restrict__ w, int nw, float* cdf, int lane) {
+__device__ __forceinline__ void build_cdf(const float* __restrict__ w, int nw, float* cdf, int lane) {
   float part = 0.f;
   for (int j = lane; j < nw; j += 64) part += __fadd_rn(w[j], 1e-5f);
   const float total = wave_sum(part);
@@ -178,7 +196,7 @@ __device__ __forceinline__ float linspace01(int k, int n) {
 
 // ascending rank sort of L values held in LDS `vals` into global `out` (ties by index).  NaNs order after every
 // number (as torch.sort does), again by index, so the ranks stay a permutation and every output slot is written.
-__device__ void rank_sort_to(const float* vals, int L, float* __restrict__ out, int lane) {
+__device__ __forceinline__ void rank_sort_to(const float* vals, int L, float* __restrict__ out, int lane) {
   for (int e0 = 0; e0 < L; e0 += 256) {   // four candidates per lane per pass
     float v[4];
     int id[4], rank[4];
@@ -188,6 +206,7 @@ __device__ void rank_sort_to(const float* vals, int L, float* __restrict__ out, 
       v[q] = id[q] < L ? vals[id[q]] : 0.f;
       rank[q] = 0;
     }
+#pragma unroll 8                      // the LDS reads of eight candidates in flight (one wave may be alone on its CU)
     for (int f = 0; f < L; ++f) {
       const float x = vals[f];
 #pragma unroll
@@ -203,6 +222,43 @@ __device__ void rank_sort_to(const float* vals, int L, float* __restrict__ out, 
   }
 }
 
+
+// Ascending sort of all[0 .. L) = [run A (n_a values) | run B] into `out`.  When both runs are already ascending -- the
+// coarse depths always are, the resampled ones are whenever the draws are (det = True: a linspace through a monotone
+// inverse CDF) -- every value's rank is its index in its own run plus a binary search in the other run (a stable
+// merge: equal values keep A before B): ~8 steps per value instead of the L comparisons of the rank sort.  The sorted
+// output is the same whichever way it is found.  Returns through `out` only.
+__device__ __forceinline__ void merge_or_rank_sort(const float* all, int n_a, int L, float* __restrict__ out, int lane) {
+  bool ascending = true;
+  for (int j = lane; j + 1 < L; j += 64)
+    if (j + 1 != n_a) ascending = ascending && (all[j] <= all[j + 1]);         // false with a NaN on either side
+  if (__all(ascending)) {
+    const float* const b = all + n_a;
+    const int n_b = L - n_a;
+    for (int id = lane; id < L; id += 64) {
+      const float v = all[id];
+      int lo = 0, hi, r;
+      if (id < n_a) {                      // #{B < v}
+        hi = n_b;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (b[mid] < v) lo = mid + 1; else hi = mid;
+        }
+        r = id + lo;
+      } else {                             // #{A <= v}
+        hi = n_a;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (all[mid] <= v) lo = mid + 1; else hi = mid;
+        }
+        r = (id - n_a) + lo;
+      }
+      out[r] = v;
+    }
+    return;
+  }
+  rank_sort_to(all, L, out, lane);
+}
 
 // z_fine = sort(cat([z, sample_pdf(mid(z), weights[1:-1], n_new)]))  for one ray (render.py:66-70).  `zr` = the ray's S
 // depths, `weights` its S compositing weights (LDS or global), `u` its n_new draws or null (linspace: det = True),
@@ -226,7 +282,7 @@ __device__ __forceinline__ void resample_merge_ray(const float* zr, const float*
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   // z_vals_fine = sort(cat([z_coarse, z_samples]))   (render.py:70)
-  rank_sort_to(all, L, z_fine_row, lane);
+  merge_or_rank_sort(all, S, L, z_fine_row, lane);
 }
 
 }  // namespace dmn

@@ -20,6 +20,7 @@
 #include "../../include/dmnerf_hip.h"
 #include "field_common.h"
 #include "field_x3.h"
+#include "field_x3_net.h"
 
 using namespace dmn;
 
@@ -27,41 +28,6 @@ namespace {
 
 // ---- tile epilogues: piece q (0..7) handles accumulator registers 2q, 2q+1 of tile t -----------
 // -> next layer's operand fragments (register 16t + r is element (r & 7) of k-step 2t + (r >> 3))
-// Inference epilogues: DENS is compile-time -- as a run-time flag every epilogue piece carried a branch that cut the MFMA
-// shadow it is scheduled into (63 branches per kernel).
-template <class P, bool RELU, bool DENS = false>
-struct EpiSplit {
-  typename P::frag* oh;
-  typename P::frag* ol;
-  float* amax;
-  float* sigma;          // density accumulation (DENS)
-  const float* dw;       // density weights of this lane-half
-  __device__ __forceinline__ void operator()(int t, int q, float x0, float x1) const {
-    if (RELU) {
-      x0 = relu_bits(x0);
-      x1 = relu_bits(x1);
-    }
-    if (DENS) *sigma = fmaf(x1, dw[16 * t + 2 * q + 1], fmaf(x0, dw[16 * t + 2 * q], *sigma));
-    if (P::kCheckRange) {
-      *amax = fmaxf(*amax, fmaxf(fabsf(x0), fabsf(x1)));
-      // materialise the running maximum here: left free, LLVM reassociates the kernel-long max chain into one
-      // tree at the end of the kernel and keeps every converted value alive until then
-      asm volatile("" : "+v"(*amax));
-    }
-    split_pair<P, true>(x0, x1, oh[2 * t + (q >> 2)], ol[2 * t + (q >> 2)], (2 * q) & 7);
-  }
-};
-// -> rgb_linear on the VALU (ReLU first; dm_nerf.py:91-93,102)
-struct EpiRgb {
-  float* rgb;            // [3] partial sums of this lane-half
-  const float* rw;       // cst + kConstRgbW + h*64
-  __device__ __forceinline__ void operator()(int t, int q, float a0, float a1) const {
-    const float x0 = relu_bits(a0), x1 = relu_bits(a1);
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-      rgb[c] = fmaf(x1, rw[c * 128 + 16 * t + 2 * q + 1], fmaf(x0, rw[c * 128 + 16 * t + 2 * q], rgb[c]));
-  }
-};
 // Training (saving) epilogues: run-time flags on purpose.  With compile-time flags (no branches) the compiler moves the
 // 128 image stores and sign-bit updates of a layer freely and the kernel needs 512 registers + 1.3 KB of spills; the
 // branches of this form keep every piece where it is written (407 registers, no scratch).
@@ -257,92 +223,26 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x3_kernel(const FieldArgs a)
   layer_x3<P, T, 8, 0>(c, cst + kConstBiasO + h * 64, act_h, act_l, pe_h, pe_l, EpiStore{out, a.ins_ch, h});
 
   } else {
-  frag act_h[16], act_l[16], nxt_h[16], nxt_l[16];
-  float sigma = 0.f;
-  const float* const dw = cst + kConstDensW + h * 128;
-  typedef EpiSplit<P, true, false> Relu;
-  typedef EpiSplit<P, true, true> ReluDens;
-  typedef EpiSplit<P, false, false> Lin;
-
-  // ---- mlps.0: position encoding (4 k-steps) -> act
-  layer_x3<P, 8, 4, 0>(c, cst + kConstBias8 + h * 128, pe_h, pe_l, pe_h, pe_l, Relu{act_h, act_l, &amax, &sigma, dw});
-  // ---- mlps.1 .. mlps.5 in ping-pong pairs (rolled: a layer pair is ~3000 instructions); mlps.5 (skip connection)
-  //      also consumes the position encoding
-  int l = 1;
-#pragma unroll 1
-  for (int it = 0; it < 2; ++it) {
-    layer_x3<P, 8, 16, 0>(c, cst + kConstBias8 + l * 256 + h * 128, act_h, act_l, pe_h, pe_l,
-                          Relu{nxt_h, nxt_l, &amax, &sigma, dw});
-    ++l;
-    layer_x3<P, 8, 16, 0>(c, cst + kConstBias8 + l * 256 + h * 128, nxt_h, nxt_l, pe_h, pe_l,
-                          Relu{act_h, act_l, &amax, &sigma, dw});
-    ++l;
-    if (it == 1) {
-      layer_x3<P, 8, 16, 4>(c, cst + kConstBias8 + l * 256 + h * 128, act_h, act_l, pe_h, pe_l,
-                            Relu{nxt_h, nxt_l, &amax, &sigma, dw});
-      ++l;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        act_h[k] = nxt_h[k];
-        act_l[k] = nxt_l[k];
-      }
-    }
-  }
-  // ---- mlps.6, and mlps.7 with the density head's partial sums (its own instantiation: DENS is compile-time)
-  layer_x3<P, 8, 16, 0>(c, cst + kConstBias8 + 6 * 256 + h * 128, act_h, act_l, pe_h, pe_l,
-                        Relu{nxt_h, nxt_l, &amax, &sigma, dw});
-  layer_x3<P, 8, 16, 0>(c, cst + kConstBias8 + 7 * 256 + h * 128, nxt_h, nxt_l, pe_h, pe_l,
-                        ReluDens{act_h, act_l, &amax, &sigma, dw});
-  // ---- density_linear (dm_nerf.py:101): fp32 partial sums were taken while mlps.7 was converted
-  sigma += __shfl_xor(sigma, 32);
-  sigma += cst[kConstDensB];
-
-  if (a.sigma_only) {
-    // Density is all the caller wants (the coarse pass of an image loop only feeds the resampler): skip the colour and
-    // instance branches, 29 % of the network.  The other channels are written as zeros so that raw stays a full row.
+    float sigma, rgb[3], insv[16 * T];
+    x3_network<P, T>(c, cst, pe_h, pe_l, qe_h, qe_l, h, a.sigma_only != 0, amax, sigma, rgb, insv);
+    // raw row of this lane's point: [rgb, sigma] by lane-half 0, the instance logits by both (dm_nerf.py:105)
     if (valid) {
       float* row = a.raw + m * (4 + a.ins_ch);
       if (h == 0) {
-        row[0] = 0.f; row[1] = 0.f; row[2] = 0.f;
+        row[0] = rgb[0]; row[1] = rgb[1]; row[2] = rgb[2];
         row[3] = sigma;
       }
 #pragma unroll
       for (int i = 0; i < 16 * T; ++i) {
         const int ch = feat_of(i, 0) + 4 * h;
-        if (ch < a.ins_ch) row[4 + ch] = 0.f;
+        if (ch < a.ins_ch) row[4 + ch] = insv[i];
       }
     }
-    if (P::kCheckRange && a.status != nullptr && !(amax < 60000.f)) atomicOr(a.status, DMN_STATUS_FP16_RANGE);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next stage's LDS-DMA must land before this LDS is released
-    return;
-  }
-
-  // ---- rgb_feature_linear (no activation) -> nxt; rgb_feature_linears.0 on [feature, dirs] -> rgb_linear
-  layer_x3<P, 8, 16, 0>(c, cst + kConstBias8 + 8 * 256 + h * 128, act_h, act_l, pe_h, pe_l,
-                        Lin{nxt_h, nxt_l, &amax, &sigma, dw});
-  float rgb[3] = {0.f, 0.f, 0.f};
-  layer_x3<P, 4, 16, 2>(c, cst + kConstBias4 + h * 64, nxt_h, nxt_l, qe_h, qe_l, EpiRgb{rgb, cst + kConstRgbW + h * 64});
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    rgb[k] += __shfl_xor(rgb[k], 32);
-    rgb[k] += cst[kConstRgbB + k];
-  }
-  float* const out = valid ? a.raw + m * (4 + a.ins_ch) : nullptr;
-  if (out != nullptr && h == 0) {
-    out[0] = rgb[0];
-    out[1] = rgb[1];
-    out[2] = rgb[2];
-    out[3] = sigma;
-  }
-
-  // ---- ins_feature_linear on the trunk output (no activation) -> nxt; ins_feature_linears.0 (ReLU) -> act[0..7]
-  layer_x3<P, 8, 16, 0>(c, cst + kConstBias8 + 9 * 256 + h * 128, act_h, act_l, pe_h, pe_l,
-                        Lin{nxt_h, nxt_l, &amax, &sigma, dw});
-  layer_x3<P, 4, 16, 0>(c, cst + kConstBias4 + 128 + h * 64, nxt_h, nxt_l, pe_h, pe_l,
-                        Relu{act_h, act_l, &amax, &sigma, dw});
-  // ---- ins_linear: 128 -> ins_num + 1, T tiles, stored straight from the accumulators
-  layer_x3<P, T, 8, 0>(c, cst + kConstBiasO + h * 64, act_h, act_l, pe_h, pe_l, EpiStore{out, a.ins_ch, h});
-
+    if (a.sigma_only) {
+      if (P::kCheckRange && a.status != nullptr && !(amax < 60000.f)) atomicOr(a.status, DMN_STATUS_FP16_RANGE);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next stage's LDS-DMA must land before this LDS is released
+      return;
+    }
   }
 #ifdef DMN_STAMPS
   {

@@ -94,7 +94,9 @@ __device__ __forceinline__ void stage_begin(Ctx& c) {
 }
 
 // piece q (0..15) of this wave's share of the NEXT stage (index c.g after stage_begin).  Past the end of the
-// stream the source clamps to the last stage and the copy lands in the buffer nobody reads any more.
+// stream the source clamps to the last stage and the copy lands in the buffer nobody reads any more.  (Skipping those
+// copies with a wave-uniform `if (c.g >= c.G) return;` was tried: where the stage counter is not a compile-time
+// constant it becomes 557 branches in the step loop, the kernels need 512 registers + 600 B of spills, -7 %.)
 __device__ __forceinline__ void load_piece(const Ctx& c, int q) {
   if (DMN_ABL_NODMA && c.g >= 2) return;
   const int g = c.g < c.G ? c.g : c.G - 1;

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void merge_kernel(MergeArgs m)
   for (int j = lane; j < m.nb; j += 64) all[m.na + j] = m.b[n * m.bs + j];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  rank_sort_to(all, L, m.out + n * L, lane);
+  merge_or_rank_sort(all, m.na, L, m.out + n * L, lane);
 }
 
 inline unsigned ew_blocks(long total) {

@@ -363,6 +363,58 @@ def composite(raw: torch.Tensor, z: torch.Tensor, rays_d: torch.Tensor, keep_las
     return rgb, weights, depth, ins
 
 
+FUSED_MIN_CHANNELS = 32      # = kWideChannels of the compositing kernels (csrc/composite_common.h)
+
+
+def fused_supported(n_samples: int, n_importance: int, ins_num: int, precision: str) -> bool:
+    """Whether ``render_fused`` covers this configuration: split-precision kernels, 64-sample passes."""
+    return (precision in ("fp16x3", "bf16x3") and n_samples % 64 == 0 and (n_samples + n_importance) % 64 == 0
+            and n_samples >= 64 and 0 <= n_importance <= 1024 and ins_num + 1 <= MAX_INS_CHANNELS)
+
+
+def field_composite(rays_o: torch.Tensor, rays_d: torch.Tensor, z: torch.Tensor, blob: torch.Tensor, ins_num: int,
+                    precision: str, sigma_only: bool = False, maps: bool = True, weights: bool = False,
+                    n_new: Optional[int] = None, u: Optional[torch.Tensor] = None):
+    """Field evaluation + compositing in one launch (``raw`` never reaches memory): returns
+    ``(rgb, depth, ins, weights, z_fine)`` with ``None`` for what was not asked for.  ``n_new`` not None: the
+    resampling + sorted merge of dm_nerf on the composited weights (``u``: draws, ``None`` = det) -> ``z_fine``."""
+    n = rays_o.shape[0]
+    rays_o = _dev(rays_o, "rays_o").contiguous()
+    rays_d = _dev(rays_d, "rays_d").contiguous()
+    zz, stride = _rows(z, n, "z_vals")
+    s = z.shape[1]
+    dev = rays_o.device
+    new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+    rgb, depth, ins = (new(n, 3), new(n), new(n, ins_num)) if maps else (None, None, None)
+    w = new(n, s) if weights else None
+    z_fine, uu, ustride = None, None, 0
+    if n_new is not None:
+        uu, ustride = _draws(u, n, n_new)
+        z_fine = new(n, s + n_new)
+    with _timed("field_fwd", n * s):
+        check(load().dmn_field_composite_x3(ptr(rays_o), ptr(rays_d), ptr(zz), stride, n, s, ptr(blob), ins_num,
+                                            precision_code(precision), int(sigma_only), ptr(rgb), ptr(depth), ptr(ins),
+                                            ptr(w), ptr(uu), ustride, n_new or 0, ptr(z_fine),
+                                            ptr(status_word(dev)), current_stream()), "dmn_field_composite_x3")
+    return rgb, depth, ins, w, z_fine
+
+
+def render_fused(rays_o: torch.Tensor, rays_d: torch.Tensor, z_coarse: torch.Tensor, blob_coarse: torch.Tensor,
+                 blob_fine: torch.Tensor, ins_num: int, precision: str, n_importance: int,
+                 u: Optional[torch.Tensor] = None, coarse_maps: bool = False, coarse_sigma_only: bool = False):
+    """One inference chunk of dm_nerf in two launches (coarse field + compositing + resampling, fine field +
+    compositing).  Returns a dict with rgb_fine, depth_fine, ins_fine, z_vals_fine (+ rgb_coarse, depth_coarse,
+    ins_coarse with ``coarse_maps``); bit-identical to the unfused chain."""
+    rgb_c, depth_c, ins_c, _, z_fine = field_composite(rays_o, rays_d, z_coarse, blob_coarse, ins_num, precision,
+                                                       sigma_only=coarse_sigma_only, maps=coarse_maps,
+                                                       n_new=int(n_importance), u=u)
+    rgb, depth, ins, _, _ = field_composite(rays_o, rays_d, z_fine, blob_fine, ins_num, precision)
+    out = {"rgb_fine": rgb, "depth_fine": depth, "ins_fine": ins, "z_vals_fine": z_fine}
+    if coarse_maps:
+        out.update({"rgb_coarse": rgb_c, "depth_coarse": depth_c, "ins_coarse": ins_c})
+    return out
+
+
 def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, n_new: int, u: Optional[torch.Tensor]) -> torch.Tensor:
     n, b = bins.shape
     bb, bstride = _rows(bins, n, "bins")

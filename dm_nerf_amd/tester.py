@@ -11,7 +11,7 @@ import warnings
 from types import SimpleNamespace
 
 from . import ops
-from .helpers import get_rays_k, z_val_sample
+from .helpers import _unit_linspace, get_rays_k, z_val_sample
 from .render import dm_nerf
 
 
@@ -21,7 +21,8 @@ def render_image(position_embedder, view_embedder, model_coarse, model_fine, c2w
     """Render one pose.  ``chunk`` defaults to ``args.N_test`` (tester.py:62); the reference's
     O(chunks^2) ``torch.cat`` growth (tester.py:72-76) is replaced by writes into preallocated
     images.  ``ray_range=(a, b)`` renders only flat rays ``[a, b)`` (multi-GPU sharding of one
-    image) and returns flat ``[b-a, .]`` tensors.  ``image_only`` (split precisions): the coarse network evaluates
+    image) and returns flat ``[b-a, .]`` tensors.  With a split precision (``args.precision``) the chunks run through the
+    fused field + compositing kernels (``ops.render_fused``).  ``image_only`` (split precisions): the coarse network evaluates
     its density only -- the colour / instance heads of the coarse pass feed nothing this loop returns
     (tester.py:70-76 keeps ``rgb_fine`` and ``ins_fine``); the returned images are bit-identical."""
     H, W, K = hwk
@@ -44,12 +45,29 @@ def render_image(position_embedder, view_embedder, model_coarse, model_fine, c2w
     n_total = hi - lo
     rgb = torch.empty(n_total, 3, dtype=torch.float32, device=rays_o.device)
     ins = torch.empty(n_total, model_fine.ins_num, dtype=torch.float32, device=rays_o.device)
+    # Split-precision modes can run field evaluation, compositing and resampling fused (ops.render_fused: two launches
+    # per chunk, `raw` never reaches memory, results bit-identical to dm_nerf()'s chain -- tests/test_gpu_parity.py).
+    # Measured on one MI355X (bf16x3, 65536-ray chunks): +2.0 % rays/s with Replica's 98-channel rows, where the chain
+    # moves 100 KB of raw per ray through HBM with scattered row stores; -1 % with DM-SR's 18 channels, where compositing
+    # is 0.6 % of a step and a lone wave per ray composites while its CU idles.  So: on by default for rows wider than
+    # the lane-per-sample compositing form (ops.FUSED_MIN_CHANNELS); args.fused = True / False overrides.
+    want = getattr(args, "fused", None)
+    if want is None:
+        want = model_fine.ins_num + 5 > ops.FUSED_MIN_CHANNELS
+    fused = (bool(want) and float(args.perturb) == 0.0
+             and ops.fused_supported(int(args.N_samples), int(args.N_importance), model_fine.ins_num, precision))
     with torch.no_grad():
         for start in range(lo, hi, chunk):                                       # tester.py:62-71
             n = min(chunk, hi - start)
             z = z_val_sample(n, args.near, args.far, args.N_samples)
-            batch = torch.stack([rays_o[start:start + n], rays_d[start:start + n]], dim=0)
-            out = dm_nerf(batch, position_embedder, view_embedder, model_coarse, model_fine, z, args)
+            if fused:
+                out = ops.render_fused(rays_o[start:start + n], rays_d[start:start + n], z,
+                                       model_coarse.blob(precision), model_fine.blob(precision), model_fine.ins_num,
+                                       precision, int(args.N_importance), coarse_sigma_only=image_only,
+                                       u=_unit_linspace(int(args.N_importance), rays_o.device.index))   # det=True
+            else:
+                batch = torch.stack([rays_o[start:start + n], rays_d[start:start + n]], dim=0)
+                out = dm_nerf(batch, position_embedder, view_embedder, model_coarse, model_fine, z, args)
             rgb[start - lo:start - lo + n] = out["rgb_fine"]
             ins[start - lo:start - lo + n] = out["ins_fine"]
     if precision == "fp16x3" and ops.take_status(rgb.device) & ops.STATUS_FP16_RANGE:

@@ -109,6 +109,28 @@ int dmn_field_fwd_rays_x3_sigma(const float* rays_o, const float* rays_d, const 
                                 long n_rays, int n_samples, const void* blob, int ins_num, int precision, float* raw,
                                 int* status, void* stream);
 
+/* ---- field evaluation + compositing (+ resampling) fused: `raw` never reaches memory ----------------------
+ * For the image loop (networks/tester.py:62-76 keeps rgb_fine / ins_fine only).  One launch evaluates the field of
+ * `precision` (split-precision kernels: DMN_PREC_FP16X3 / DMN_PREC_BF16X3) on o + d*z, composites every ray as
+ * dmn_composite_fwd does (render_train, networks/render.py:6-28; keep_last = 0) and, when z_fine != NULL, runs the
+ * resampling of dmn_resample_merge on the ray's weights (networks/render.py:66-70: draws u as there, NULL = det).
+ * rgb [N,3], depth [N], ins [N,ins_num], weights [N,S] may each be NULL.  sigma_only: the network stops behind its
+ * density head (colour / instance channels composite as zeros).  n_samples must be a multiple of 64 (a workgroup walks
+ * two rays in 64-sample passes), else DMN_ERR_UNSUPPORTED.  Bit-identical to the unfused entry points.             */
+int dmn_field_composite_x3(const float* rays_o, const float* rays_d, const float* z, long z_ray_stride, long n_rays,
+                           int n_samples, const void* blob, int ins_num, int precision, int sigma_only, float* rgb,
+                           float* depth, float* ins, float* weights, const float* u, long u_ray_stride, int n_new,
+                           float* z_fine, int* status, void* stream);
+
+/* The inference chunk of dm_nerf in two such launches: coarse field + compositing + resampling -> z_fine
+ * [N, n_samples + n_importance] (caller-owned; z_vals_fine of networks/render.py:70), fine field + compositing ->
+ * rgb_fine / depth_fine / ins_fine.  Coarse maps may be NULL; coarse_sigma_only as above.                          */
+int dmn_render_fused(const float* rays_o, const float* rays_d, const float* z_coarse, long z_ray_stride,
+                     const float* u, long u_ray_stride, long n_rays, int n_samples, int n_importance,
+                     const void* blob_coarse, const void* blob_fine, int ins_num, int precision,
+                     int coarse_sigma_only, float* z_fine, float* rgb_fine, float* depth_fine, float* ins_fine,
+                     float* rgb_coarse, float* depth_coarse, float* ins_coarse, int* status, void* stream);
+
 /* ---- the whole chunk in one call: dm_nerf (networks/render.py:31-96) ------------------------------------
  * (stratified jitter with t_rand, or none when NULL ->) coarse field -> compositing -> inverse-CDF resampling
  * (draws u, or the det = True lattice when NULL) + sorted merge -> fine field -> compositing, all enqueued on

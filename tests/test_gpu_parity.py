@@ -222,6 +222,19 @@ def test_merge_is_sorted_and_is_a_permutation():
     b[0, :10] = a[0, :10]                                         # ties
     out = H(ops.merge_depths(G(a), G(b)))
     np.testing.assert_array_equal(out, np.sort(np.concatenate([a, b], -1), -1))
+    # both runs ascending (the render path's case: lattice + monotone resampled depths): the merge by binary search,
+    # with ties inside and across the runs, an empty run, and a NaN that sends one ray back to the rank sort
+    bs = np.sort(b, -1)
+    bs[1, 5:9] = bs[1, 5]
+    bs[2, :3] = a[2, 7]
+    out = H(ops.merge_depths(G(a), G(bs)))
+    np.testing.assert_array_equal(out, np.sort(np.concatenate([a, bs], -1), -1))
+    np.testing.assert_array_equal(H(ops.merge_depths(G(a), G(bs[:, :0]))), a)
+    bn = bs.copy()
+    bn[4, 17] = np.nan
+    out = H(ops.merge_depths(G(a), G(bn)))
+    np.testing.assert_array_equal(out[:4], np.sort(np.concatenate([a, bn], -1), -1)[:4])
+    np.testing.assert_array_equal(out[4], np.sort(np.concatenate([a[4], bn[4]])))          # NaN last, as torch.sort
 
 
 def test_jitter_matches_oracle():
@@ -647,17 +660,27 @@ def test_training_gradients_match_reference_golden(golden, precision):
             err = rel_err(got, g[f"{tag}.{name}"])
             l2 = float(np.linalg.norm((got - g[f"{tag}.{name}"]).astype(np.float64))
                        / max(np.linalg.norm(g[f"{tag}.{name}"].astype(np.float64)), 1e-30))
-            print(f"   {precision} {tag}.{name}: max-rel {err:.2e}  l2-rel {l2:.2e}")
             worst = max(worst, err)
-            # Coarse-network gradients do not see the sampler: 1e-4.  Fine-network gradients are evaluated at the
-            # resampled depths, and the reference disagrees with ITSELF there by 3.5e-2 (its fp64 run against
-            # these fp32 goldens; cumprod's backward divides by 1 - alpha + 1e-10): 5e-2 end to end, and
-            # test_fine_stage_gradients_on_golden_depths holds the fine stage itself to 5e-3.
-            # With precision != "fp32" the training forward runs in bf16x3 (1e-5 on the activations): a handful of
-            # ReLUs of the 3072 points sit on the other side of zero, and the compositing gradient concentrates on few
-            # samples per ray, so one such unit moves a gradient by up to 2.5e-2 of its scale (observed, mlps.5.bias);
-            # test_field_backward_kernels_match_library_gemm_backward holds that mode to 1e-4 away from such units.
-            assert err < (1e-4 if (tag == "c" and precision == "fp32") else 5e-2), (tag, name, err)
+            # Observed on MI355X (max-abs / max-magnitude, and relative L2), caps at ~2x:
+            #   exact forward: coarse network 2.1e-5 / 1.6e-5 -- it does not see the sampler, held to 5e-5.  The fine
+            #     network is evaluated at the resampled depths, where the reference disagrees with ITSELF by 3.5e-2
+            #     (its fp64 run against these fp32 goldens; cumprod's backward divides by 1 - alpha + 1e-10):
+            #     9.8e-3 / 6.9e-3 observed; test_fine_stage_gradients_on_golden_depths holds that stage alone to 5e-3.
+            #   split-precision forward (bf16x3, 7e-6 on the activations): a handful of ReLUs of the 3072 points sit on
+            #     the other side of zero and the compositing gradient concentrates on few samples per ray, so the
+            #     gradients that pass through a ReLU mask of this network move by up to 2.5e-2 in single entries
+            #     (6.9e-3 in L2; fine network 2.9e-2 / 2.0e-2).  The parameters whose gradient passes through no mask
+            #     of the perturbed forward (the detached instance branch, the density and colour heads) keep 1e-5 and
+            #     are held to 1e-4; test_field_backward_kernels_match_library_gemm_backward holds the masked ones to
+            #     1e-4 away from units at zero.
+            mask_free = name.startswith(("ins_", "density_linear", "rgb_linear"))
+            if precision == "fp32":
+                cap_max, cap_l2 = (5e-5, 5e-5) if tag == "c" else (2e-2, 1.4e-2)
+            elif tag == "c":
+                cap_max, cap_l2 = (1e-4, 1e-4) if mask_free else (5e-2, 1.4e-2)
+            else:
+                cap_max, cap_l2 = 6e-2, 4e-2
+            assert err < cap_max and l2 < cap_l2, (tag, name, err, l2)
     print(f"{precision}: worst gradient rel err {worst:.2e}")
     # an optimizer step through the standard torch API works on the module's parameters (train_dmsr.py:127-128)
     opt = torch.optim.Adam(list(coarse.parameters()) + list(fine.parameters()), lr=5e-4, betas=(0.9, 0.999))
@@ -764,12 +787,12 @@ def test_field_backward_kernels_match_library_gemm_backward(ins_num, n, s, fwd, 
     g_raw = rng.standard_normal((n, s, 5 + ins_num)).astype(np.float32)
     # A ReLU whose pre-activation is within rounding of zero may open in one forward and close in the other; that
     # is a different function, not an error.  Points with such a unit get no gradient in this comparison.
-    # (the bf16x3 forward differs from torch's by ~1e-5 of the activation scale, the exact one by ~1e-6)
+    # (the bf16x3 forward differs from torch's by ~1e-5 of the activation scale, the exact one by ~1e-6; the thresholds
+    # are 3x / 10x that)
     low = H(_min_abs_preactivation(net, G(o), G(d), G(z)))
-    fragile = low < (1e-5 if fwd == "fp32" else 1e-4)
-    print(f"fragile points: {fragile.mean():.3f} (|pre-activation| < 1e-5: {(low < 1e-5).mean():.3f}, < 3e-5: "
-          f"{(low < 3e-5).mean():.3f}, < 1e-4: {(low < 1e-4).mean():.3f})")
-    assert fragile.mean() < (0.25 if fwd == "fp32" else 0.9)
+    # observed: 12..18 % of the points have a unit within 1e-5 of zero, 42 % within 3e-5 (2816 ReLU units per point)
+    fragile = low < (1e-5 if fwd == "fp32" else 3e-5)
+    assert fragile.mean() < (0.25 if fwd == "fp32" else 0.5)
     g_raw[fragile] = 0.0
     grads = {}
     for tag, fn in (("hip", FieldFn), ("lib", FieldFnLibrary)):
@@ -1022,6 +1045,78 @@ def test_image_only_coarse_pass_gives_bit_identical_images(precision):
     assert float(part[..., :3].abs().max()) == 0.0 and float(part[..., 4:].abs().max()) == 0.0
     with pytest.raises(ValueError):
         ops.field_rays(G(o), G(d), z, coarse.blob("fp32"), 13, "fp32", sigma_only=True)
+
+
+# ---- field + compositing (+ resampling) fused in one kernel: the image loop's path in the split precisions ---------
+@pytest.mark.parametrize("precision", ["bf16x3", "fp16x3"])
+@pytest.mark.parametrize("ins_num,n_rays,n_samples", [(13, 37, 64), (13, 6, 192), (93, 9, 64), (93, 4, 192), (127, 3, 128),
+                                                      (0, 2, 64)])
+def test_fused_field_composite_is_bit_identical_to_the_chain(precision, ins_num, n_rays, n_samples):
+    """dmn_field_composite_x3 (field evaluation, compositing and resampling in one kernel; raw rows parked in LDS) against
+    dmn_field_fwd_rays_x3 -> dmn_composite_fwd -> dmn_resample_merge: every output, bit for bit.  Odd ray counts (a
+    workgroup owns two rays), 1 / 2 / 3 passes of 64 samples, narrow and wide rows (C = 18 / 98 / 132 / 5), recorded
+    draws and the det = True lattice, and the density-only mode."""
+    rng = np.random.default_rng(1000 * ins_num + n_rays)
+    params = oracle.make_params(ins_num, 7)
+    model = dm.DM_NeRF(8, 256, 63, 27, [4], ins_num).to(DEV)
+    model.load_state_dict(params)
+    blob = model.blob(precision)
+    o = G(rng.uniform(-1, 1, size=(n_rays, 3)).astype(np.float32))
+    d = G(rng.standard_normal((n_rays, 3)).astype(np.float32))
+    z = G(np.sort(rng.uniform(cases.NEAR, cases.FAR, size=(n_rays, n_samples)).astype(np.float32), -1))
+    u = G(rng.uniform(0, 1, size=(n_rays, 128)).astype(np.float32))
+    raw = ops.field_rays(o, d, z, blob, ins_num, precision)
+    rgb, w, depth, ins = ops.composite(raw, z, d)
+    for draws in (u, None):
+        z_fine = ops.resample_merge(z, w, 128, draws)
+        got = ops.field_composite(o, d, z, blob, ins_num, precision, weights=True, n_new=128, u=draws)
+        for name, a, b in (("rgb", got[0], rgb), ("depth", got[1], depth), ("ins", got[2], ins), ("weights", got[3], w),
+                           ("z_fine", got[4], z_fine)):
+            np.testing.assert_array_equal(H(a), H(b), err_msg=f"{name} (draws given: {draws is not None})")
+    # shared lattice row (stride 0), maps only
+    lat = z[:1].expand(n_rays, n_samples)
+    raw_l = ops.field_rays(o, d, lat, blob, ins_num, precision)
+    rgb_l, _, depth_l, ins_l = ops.composite(raw_l, lat, d)
+    got = ops.field_composite(o, d, lat, blob, ins_num, precision)
+    assert got[3] is None and got[4] is None
+    for a, b in ((got[0], rgb_l), (got[1], depth_l), (got[2], ins_l)):
+        np.testing.assert_array_equal(H(a), H(b))
+    # density-only coarse pass: weights and resampled depths unchanged
+    got = ops.field_composite(o, d, z, blob, ins_num, precision, sigma_only=True, maps=False, weights=True, n_new=128, u=u)
+    assert got[0] is None
+    np.testing.assert_array_equal(H(got[3]), H(w))
+    np.testing.assert_array_equal(H(got[4]), H(ops.resample_merge(z, w, 128, u)))
+    assert ops.take_status(DEV) == 0
+    with pytest.raises(dm.HipLibraryError):                                  # 64-sample passes only
+        ops.field_composite(o, d, z[:, :50].contiguous(), blob, ins_num, precision)
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "fp16x3"])
+def test_image_loop_fused_path_equals_the_chained_path(precision):
+    """render_image in a split precision runs ops.render_fused; args.fused = False runs dm_nerf()'s chain: same bits,
+    ragged last chunk with an odd ray count, with and without the density-only coarse pass, Replica-wide rows."""
+    for ins_num, (Hh, W), near, far in ((13, (21, 25), cases.NEAR, cases.FAR), (93, (9, 15), 0.0, 6.5)):
+        pos, view, coarse, fine, args = nets(ins_num, 3, 5)
+        args.precision, args.near, args.far = precision, near, far
+        hwk = [Hh, W, cases.study_intrinsics(Hh, W)]
+        c2w = cases.study_c2w()
+        plain = SimpleNamespace(**{**vars(args), "fused": False})
+        forced = SimpleNamespace(**{**vars(args), "fused": True})
+        a = dm.render_image(pos, view, coarse, fine, c2w, hwk, forced, chunk=200)
+        b = dm.render_image(pos, view, coarse, fine, c2w, hwk, plain, chunk=200)
+        c = dm.render_image(pos, view, coarse, fine, c2w, hwk, forced, chunk=200, image_only=True)
+        auto = dm.render_image(pos, view, coarse, fine, c2w, hwk, args, chunk=200)        # the default rule, either way
+        np.testing.assert_array_equal(H(auto[0]), H(b[0]))
+        for x, y in ((a[0], b[0]), (a[1], b[1]), (c[0], b[0]), (c[1], b[1])):
+            np.testing.assert_array_equal(H(x), H(y))
+    out = ops.render_fused(*[t.reshape(-1, 3) for t in dm.get_rays_k(Hh, W, hwk[2], c2w)],
+                           dm.z_val_sample(Hh * W, near, far, 64), coarse.blob(precision), fine.blob(precision), ins_num,
+                           precision, 128, coarse_maps=True)
+    with torch.no_grad():
+        rays = torch.stack([t.reshape(-1, 3) for t in dm.get_rays_k(Hh, W, hwk[2], c2w)], 0)
+        want = dm.dm_nerf(rays, pos, view, coarse, fine, dm.z_val_sample(Hh * W, near, far, 64), plain)
+    for k in ("rgb_fine", "depth_fine", "ins_fine", "z_vals_fine", "rgb_coarse", "depth_coarse", "ins_coarse"):
+        np.testing.assert_array_equal(H(out[k]), H(want[k]), err_msg=k)
 
 
 # ---- object manipulation (row N3), pinned by the reference's own functions (G12) ------------------------------

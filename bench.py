@@ -109,12 +109,32 @@ def training_leg(nerf, K, pose, device, n_rays: int = 4096, steps: int = 4):
             penalizer=lambda raw, zz, depth: dm.ins_penalizer(raw, zz, depth, rays[1], targs))
         run(0)
         torch.cuda.synchronize()
+        ops.PROFILE = []
         t0 = time.perf_counter()
         for i in range(steps):
             last = run(i + 1)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
-        result[f"forward_{prec}"] = {"ms_per_step": dt * 1e3, "rays_per_s": n_rays / dt, "loss_total": last["total"]}
+        prof, ops.PROFILE = ops.PROFILE, None
+        entry = {"ms_per_step": dt * 1e3, "rays_per_s": n_rays / dt, "loss_total": last["total"], "kernels_ms_per_step": {}}
+        for name in ("field_fwd_save", "field_bwd_data", "field_bwd_weights"):
+            _, secs, _ = kernel_stats(prof, name)
+            entry["kernels_ms_per_step"][name] = secs / steps * 1e3
+        # the HBM-bound part of the step: the weight-gradient GEMMs read both records (save: activations, gradient: dL/d
+        # pre-activation) as [row][32 points] images; algorithmic bytes = 128 B per 32-row tile per point summed over the
+        # 17 GEMMs' operands (field_layout.h wgemm_table: 212 row tiles at ins_num = 13 -> 27.1 KB per point)
+        points = n_rays * (2 * N_SAMPLES + N_IMPORTANCE)
+        wg_bytes = points * 212 * 128
+        t_wg = entry["kernels_ms_per_step"]["field_bwd_weights"] * 1e-3
+        entry["roofline_weight_gradients"] = {
+            "kernel": "field_wgrad_x3_kernel<8,8,2,2> + the small GEMM classes + field_wgrad_reduce_kernel (one event "
+                      "around dmn_field_bwd_weights, both networks)", "bound": "hbm", "achieved": wg_bytes / t_wg / 1e9,
+            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": wg_bytes / t_wg / 1e9 / PEAK_HBM_GBS,
+            "algorithmic_bytes_per_step": wg_bytes,
+            "traffic": 29.1e9 if INS_NUM == 13 and n_rays == 4096 else None,      # 28.46 GB fetched + 0.64 GB of partials written
+            "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per step, profiles/r01e_train_hbm_traffic.txt "
+                              "(kernels unchanged since)"}
+        result[f"forward_{prec}"] = entry
     coarse.load_state_dict(state[0]); fine.load_state_dict(state[1])
     coarse.eval(); fine.eval()
     return result

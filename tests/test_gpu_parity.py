@@ -132,6 +132,12 @@ def test_blob_follows_parameter_updates():
         model.density_linear.bias.add_(1.0)
     b1 = model.blob()
     assert b1 is not b0 and not torch.equal(b0, b1)
+    # a write through .data bypasses autograd's version counter (by design): the cache cannot see it, invalidate_blobs() does
+    model.density_linear.bias.data.add_(1.0)
+    assert model.blob() is b1
+    model.invalidate_blobs()
+    b2 = model.blob()
+    assert b2 is not b1 and not torch.equal(b1, b2)
     sd = {k: v.cpu() for k, v in model.state_dict().items()}
     assert list(sd) == [k for k, _ in oracle.param_specs(13)]   # checkpoint key contract
 

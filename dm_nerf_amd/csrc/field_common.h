@@ -39,17 +39,23 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-// slots 2.. of an encoding register file: sin (half 0) / cos (half 1) of 2^f * coordinate
+// slots 2.. of an encoding register file: sin (half 0) / cos (half 1) of 2^f * coordinate, f = 0 .. NF-1, by the
+// double-angle recurrence of trig.h from one fp64 sincos per coordinate
 template <int NF>
 __device__ __forceinline__ void encode_regs(float* e, float x, float y, float zc, int h) {
   e[0] = h ? zc : x;
   e[1] = h ? 0.f : y;
+  double sn[3], cs[3];
+  sincos_f64(x, sn[0], cs[0]);
+  sincos_f64(y, sn[1], cs[1]);
+  sincos_f64(zc, sn[2], cs[2]);
 #pragma unroll
   for (int f = 0; f < NF; ++f) {
-    const float sc = (float)(1 << f);           // exact power of two: x*freq is exact (dm_nerf.py:25,31)
-    e[2 + 3 * f + 0] = trig_sel(x * sc, h);
-    e[2 + 3 * f + 1] = trig_sel(y * sc, h);
-    e[2 + 3 * f + 2] = trig_sel(zc * sc, h);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      e[2 + 3 * f + k] = (float)(h ? cs[k] : sn[k]);
+      if (f + 1 < NF) double_angle(sn[k], cs[k]);
+    }
   }
 }
 

@@ -123,6 +123,41 @@ def test_field_forward_on_rays_matches_oracle(n_rays, n_samples, ins_num):
     np.testing.assert_array_equal(raw_l, raw_m)
 
 
+def test_in_kernel_encodings_match_the_reference_encoder():
+    """The field kernels build their own encodings (one fp64 sincos per coordinate, then the double-angle recurrence over
+    the power-of-two bands).  The saving forward writes them into its record: read them back and hold them to the
+    reference's Embedder (torch fp32 sin / cos of the fp32 argument) at the stand-alone encoder's tolerance, 2e-7 abs,
+    on coordinates up to +-15 (arguments to 7.7e3 rad)."""
+    rng = np.random.default_rng(77)
+    n, s = 8, 32                                               # 8 tiles of 32 points
+    o = rng.uniform(-3, 3, size=(n, 3)).astype(np.float32)
+    d = rng.standard_normal((n, 3)).astype(np.float32)
+    z = np.sort(rng.uniform(0.5, 8.0, size=(n, s)).astype(np.float32), -1)
+    model = dm.DM_NeRF(8, 256, 63, 27, [4], 13).to(DEV)
+    model.load_state_dict(oracle.make_params(13, 0))
+    for precision in ("fp32", "bf16x3"):
+        _, save = ops.field_rays_save(G(o), G(d), G(z), model.blob(precision), 13, precision)
+        rec = H(save).reshape(n, -1, 64)[:, :48]               # per tile: 32 position + 16 view registers x 64 lanes
+        pts = (torch.from_numpy(o)[:, None, :] + torch.from_numpy(d)[:, None, :] * torch.from_numpy(z)[:, :, None])
+        view = torch.from_numpy(d) / torch.norm(torch.from_numpy(d), dim=-1, keepdim=True)
+        want_p = oracle.encode(pts.reshape(-1, 3), 10).numpy().reshape(n, s, 63)
+        want_v = oracle.encode(view[:, None, :].expand(n, s, 3).reshape(-1, 3), 4).numpy().reshape(n, s, 27)
+        assert 11.0 < np.abs(pts.numpy()).max() < 20.0
+        worst = 0.0
+        for h in range(2):
+            for j in range(32):                                # field_layout.h pos_slot(j, h)
+                col = (0 if h == 0 else 2) if j == 0 else ((1 if h == 0 else -1) if j == 1 else
+                                                           3 + 6 * ((j - 2) // 3) + 3 * h + (j - 2) % 3)
+                if col >= 0:
+                    worst = max(worst, float(np.abs(rec[:, j, 32 * h:32 * h + 32] - want_p[:, :, col]).max()))
+            for j in range(14):                                # dir_slot(j, h)
+                col = (0 if h == 0 else 2) if j == 0 else ((1 if h == 0 else -1) if j == 1 else
+                                                           3 + 6 * ((j - 2) // 3) + 3 * h + (j - 2) % 3)
+                if col >= 0:
+                    worst = max(worst, float(np.abs(rec[:, 32 + j, 32 * h:32 * h + 32] - want_v[:, :, col]).max()))
+        assert worst <= 2e-7, (precision, worst)
+
+
 def test_blob_follows_parameter_updates():
     model = dm.DM_NeRF(8, 256, 63, 27, [4], 13).to(DEV)
     model.load_state_dict(oracle.make_params(13, 0))

@@ -366,12 +366,17 @@ __global__ __launch_bounds__(256, 1) void field_wgrad_x3_kernel(const WgArgs a) 
     }
   };
 
+  // timing-only ablations (never in the product build): DMN_WG_ABL 1 = convert / stage only the first tile,
+  // 2 = fetch only the first tile, 3 = both
+#ifndef DMN_WG_ABL
+#define DMN_WG_ABL 0
+#endif
   if (t0 < t1) fetch(t0);
   for (long t = t0; t < t1; ++t) {
     __syncthreads();                       // everybody is done reading the previous tile
-    stage();
+    if (!((DMN_WG_ABL & 1) && t > t0)) stage();
     __syncthreads();
-    if (t + 1 < t1) fetch(t + 1);          // in flight under this tile's MFMAs
+    if (t + 1 < t1 && !(DMN_WG_ABL & 2)) fetch(t + 1);          // in flight under this tile's MFMAs
     const char* pa = lds + (wr * OTW * 32 + l) * RB + kh * 16;
     const char* pb = lds + (OT * 32 + wc * KTW * 32 + l) * RB + kh * 16;
 #pragma unroll

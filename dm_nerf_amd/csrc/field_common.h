@@ -38,6 +38,24 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
+// The same with the global address as wave-uniform base (SGPR pair) + 32-bit lane offset (one VGPR, the same for every
+// piece): `global_load_lds_dwordx4 v_off, s[base:base+1]`.  The base advances by scalar adds; the C builtin always takes
+// the per-lane 64-bit address form (a v_lshl_add_u64 per piece).  Inline asm: the compiler does not count these loads
+// in vmcnt, so whoever consumes the LDS bytes waits explicitly (stage_begin does: s_waitcnt vmcnt(0) before its barrier).
+#ifndef DMN_GLDS_ASM
+#define DMN_GLDS_ASM 1
+#endif
+__device__ __forceinline__ void glds16_u(const char* base_uniform, unsigned lane_bytes, void* l) {
+#if DMN_GLDS_ASM
+  const unsigned lds_addr = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)l;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+               : : "s"(lds_addr), "v"(lane_bytes), "s"(base_uniform) : "m0");
+#else
+  __builtin_amdgcn_global_load_lds(
+      (const __attribute__((address_space(1))) void*)(base_uniform + (unsigned long)lane_bytes),
+      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+#endif
+}
 
 // slots 2.. of an encoding register file: sin (half 0) / cos (half 1) of 2^f * coordinate, f = 0 .. NF-1, by the
 // double-angle recurrence of trig.h from one fp64 sincos per coordinate

@@ -12,16 +12,18 @@ constexpr int kLdsFloats = 2 * kStageFloats + kConstFloats;   // 80,896 B
 
 // each wave DMA-copies 8 of the stage's 32 chunks
 __device__ __forceinline__ void load_stage(const float* stream, int g, float* buf, int wave_s, int lane) {
-  const float* src = stream + (long)g * kStageFloats + wave_s * 8 * kChunkFloats + lane * 4;
+  const float* src = stream + (long)g * kStageFloats + wave_s * 8 * kChunkFloats;      // wave-uniform
   float* dst = buf + wave_s * 8 * kChunkFloats;
 #pragma unroll
-  for (int q = 0; q < 8; ++q) glds16(src + q * kChunkFloats, dst + q * kChunkFloats);
+  for (int q = 0; q < 8; ++q)
+    glds16_u(reinterpret_cast<const char*>(src + q * kChunkFloats), (unsigned)lane * 16u, dst + q * kChunkFloats);
 }
 
 // Barrier that retires stage g (DMA landed, everybody done with stage g-1), then prefetch of
 // stage g+1 into the other buffer.  Returns this lane's read base inside stage g.
 __device__ __forceinline__ const float* stage_begin(const float* stream, int g, int G, float* lds, int wave_s,
                                                     int lane) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA of stage g (inline asm: not in the compiler's count)
   __syncthreads();
   if (g + 1 < G) load_stage(stream, g + 1, lds + ((g + 1) & 1) * kStageFloats, wave_s, lane);
   return lds + (g & 1) * kStageFloats + lane * 4;

@@ -64,10 +64,10 @@ struct Ctx {
 
 // each wave DMA-copies 16 of the stage's 64 chunks
 __device__ __forceinline__ void load_stage(const Ctx& c, int g) {
-  const char* src = c.stream + (long)g * kX3StageBytes + (c.wave_s * 16) * 1024 + c.lane * 16;
+  const char* src = c.stream + (long)g * kX3StageBytes + (c.wave_s * 16) * 1024;
   char* dst = c.lds + (g & 1) * kX3StageBytes + (c.wave_s * 16) * 1024;
 #pragma unroll
-  for (int q = 0; q < 16; ++q) glds16(src + q * 1024, dst + q * 1024);
+  for (int q = 0; q < 16; ++q) glds16_u(src + q * 1024, (unsigned)c.lane * 16u, dst + q * 1024);
 }
 
 // Barrier that retires stage g (its DMA has landed, every wave is done with stage g-1).  The DMA of stage
@@ -87,6 +87,7 @@ __device__ __forceinline__ void stage_begin(Ctx& c) {
   c.t_dma += t1 - t0;
   c.t_bar += t2 - t1;
 #else
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces (inline asm: not in the compiler's count)
   __syncthreads();
 #endif
   c.buf = c.lds + (c.g & 1) * kX3StageBytes + c.lane * 16;
@@ -100,9 +101,9 @@ __device__ __forceinline__ void stage_begin(Ctx& c) {
 __device__ __forceinline__ void load_piece(const Ctx& c, int q) {
   if (DMN_ABL_NODMA && c.g >= 2) return;
   const int g = c.g < c.G ? c.g : c.G - 1;
-  const char* src = c.stream + (long)g * kX3StageBytes + (c.wave_s * 16 + q) * 1024 + c.lane * 16;
+  const char* src = c.stream + (long)g * kX3StageBytes + (c.wave_s * 16 + q) * 1024;
   char* dst = c.lds + (c.g & 1) * kX3StageBytes + (c.wave_s * 16 + q) * 1024;
-  glds16(src, dst);
+  glds16_u(src, (unsigned)c.lane * 16u, dst);
 }
 
 // PIN keeps the conversion where it is written (in the MFMA shadow of the next tile): without it the compiler

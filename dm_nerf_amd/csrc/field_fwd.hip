@@ -19,6 +19,9 @@
 
 #include "../../include/dmnerf_hip.h"
 #include "field_common.h"
+#ifndef DMN_F32_SPREAD
+#define DMN_F32_SPREAD 1
+#endif
 #include "field_stream.h"
 
 using namespace dmn;
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(256, 1) void field_fwd_kernel(const FieldArgs a) {
   constexpr int JS = inso_groups_per_stage(T);
 #pragma unroll
   for (int st = 0; st < inso_stages(T); ++st) {
-    buf = stage_begin(stream, g, G, lds, wave_s, lane);
+    buf = stage_begin(stream, g, G, lds, wave_s, lane, true);      // short stages: their successor in a burst
 #pragma unroll
     for (int jl = 0; jl < JS; ++jl) {
 #pragma unroll

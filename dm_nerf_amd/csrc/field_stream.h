@@ -19,15 +19,36 @@ __device__ __forceinline__ void load_stage(const float* stream, int g, float* bu
     glds16_u(reinterpret_cast<const char*>(src + q * kChunkFloats), (unsigned)lane * 16u, dst + q * kChunkFloats);
 }
 
-// Barrier that retires stage g (DMA landed, everybody done with stage g-1), then prefetch of
+// DMN_F32_SPREAD (set by a translation unit before including this file): the 8 pieces of the next stage are not issued
+// in a burst behind the stage barrier (where the matrix pipe waits for them: ~4 % of a stage) but one per two k-steps,
+// each right behind that k-step's MFMAs (DMN_STAGE8 / DMN_STAGE4 below).
+#ifndef DMN_F32_SPREAD
+#define DMN_F32_SPREAD 0
+#endif
+
+// Barrier that retires stage g (DMA landed, everybody done with stage g-1), then -- `burst` -- prefetch of
 // stage g+1 into the other buffer.  Returns this lane's read base inside stage g.
 __device__ __forceinline__ const float* stage_begin(const float* stream, int g, int G, float* lds, int wave_s,
-                                                    int lane) {
+                                                    int lane, bool burst = !DMN_F32_SPREAD) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA of stage g (inline asm: not in the compiler's count)
   __syncthreads();
-  if (g + 1 < G) load_stage(stream, g + 1, lds + ((g + 1) & 1) * kStageFloats, wave_s, lane);
+  if (burst && g + 1 < G) load_stage(stream, g + 1, lds + ((g + 1) & 1) * kStageFloats, wave_s, lane);
   return lds + (g & 1) * kStageFloats + lane * 4;
 }
+
+// piece q (0..7) of this wave's share of stage g_next; past the end of the stream the source clamps to the last stage
+// and the copy lands in the buffer nobody reads any more (a select, not a branch: see field_x3.h load_piece)
+__device__ __forceinline__ void load_piece32(const float* stream, int g_next, int G, float* lds, int wave_s, int lane,
+                                             int q) {
+  const int gs = g_next < G ? g_next : G - 1;
+  const float* src = stream + (long)gs * kStageFloats + (wave_s * 8 + q) * kChunkFloats;
+  float* dst = lds + (g_next & 1) * kStageFloats + (wave_s * 8 + q) * kChunkFloats;
+  glds16_u(reinterpret_cast<const char*>(src), (unsigned)lane * 16u, dst);
+}
+#define DMN_PIECE(Q)                                                              \
+  do {                                                                            \
+    if (DMN_F32_SPREAD) load_piece32(stream, g + 1, G, lds, wave_s, lane, (Q));   \
+  } while (0)
 
 __device__ __forceinline__ void bias_tiles8(f32x16* acc, const float* b) {
 #pragma unroll
@@ -70,6 +91,7 @@ __device__ __forceinline__ void bias_tiles(f32x16* acc, const float* b) {
       acc[5] = DMN_MFMA(a1.y, bv, acc[5]);                                                \
       acc[6] = DMN_MFMA(a1.z, bv, acc[6]);                                                \
       acc[7] = DMN_MFMA(a1.w, bv, acc[7]);                                                \
+      if ((jj & 1) == 0) DMN_PIECE(jj >> 1);                                              \
       a0 = n0;                                                                            \
       a1 = n1;                                                                            \
     }                                                                                     \
@@ -96,6 +118,7 @@ __device__ __forceinline__ void bias_tiles(f32x16* acc, const float* b) {
       acc2[1] = DMN_MFMA(a1.y, b1, acc2[1]);                                              \
       acc2[2] = DMN_MFMA(a1.z, b1, acc2[2]);                                              \
       acc2[3] = DMN_MFMA(a1.w, b1, acc2[3]);                                              \
+      if (((jj >> 1) % ((NK) / 16)) == 0) DMN_PIECE((jj >> 1) / ((NK) / 16));             \
       a0 = n0;                                                                            \
       a1 = n1;                                                                            \
     }                                                                                     \

@@ -28,6 +28,32 @@ namespace {
 
 // ---- tile epilogues: piece q (0..7) handles accumulator registers 2q, 2q+1 of tile t -----------
 // -> next layer's operand fragments (register 16t + r is element (r & 7) of k-step 2t + (r >> 3))
+// ---- helpers of the saving epilogues: one store instruction per value and no address arithmetic on the vector unit --
+// base = the tile's 16 image rows (wave-uniform: an SGPR pair advanced by scalar adds), per-lane offset lane * 4 in one
+// VGPR, the row as the instruction's immediate; sign bit of a post-ReLU value (+0 or positive) as min(bits, 1) shifted
+// in: two instructions instead of compare + select + shift + or.  Inline asm so that the forms survive the optimiser.
+template <int ROW>
+__device__ __forceinline__ void image_row_store(const float* tile_rows, unsigned lane_bytes, float x) {
+  asm volatile("global_store_dword %0, %1, %2 offset:%3" : : "v"(lane_bytes), "v"(x), "s"(tile_rows), "n"(ROW * 256));
+}
+__device__ __forceinline__ void image_pair_store(const float* tile_rows, unsigned lane_bytes, int q, float x0, float x1) {
+  switch (q) {      // q is a compile-time constant where this is inlined (unrolled epilogue pieces)
+    case 0: image_row_store<0>(tile_rows, lane_bytes, x0); image_row_store<1>(tile_rows, lane_bytes, x1); break;
+    case 1: image_row_store<2>(tile_rows, lane_bytes, x0); image_row_store<3>(tile_rows, lane_bytes, x1); break;
+    case 2: image_row_store<4>(tile_rows, lane_bytes, x0); image_row_store<5>(tile_rows, lane_bytes, x1); break;
+    case 3: image_row_store<6>(tile_rows, lane_bytes, x0); image_row_store<7>(tile_rows, lane_bytes, x1); break;
+    case 4: image_row_store<8>(tile_rows, lane_bytes, x0); image_row_store<9>(tile_rows, lane_bytes, x1); break;
+    case 5: image_row_store<10>(tile_rows, lane_bytes, x0); image_row_store<11>(tile_rows, lane_bytes, x1); break;
+    case 6: image_row_store<12>(tile_rows, lane_bytes, x0); image_row_store<13>(tile_rows, lane_bytes, x1); break;
+    default: image_row_store<14>(tile_rows, lane_bytes, x0); image_row_store<15>(tile_rows, lane_bytes, x1); break;
+  }
+}
+__device__ __forceinline__ void sign_bit_or(unsigned& w, float x, int bit) {
+  unsigned b;
+  asm volatile("v_min_u32 %0, 1, %1" : "=v"(b) : "v"(__float_as_uint(x)));
+  asm volatile("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(w) : "v"(b), "v"(bit));
+}
+
 // Training (saving) epilogues: run-time flags on purpose.  With compile-time flags (no branches) the compiler moves the
 // 128 image stores and sign-bit updates of a layer freely and the kernel needs 512 registers + 1.3 KB of spills; the
 // branches of this form keep every piece where it is written (407 registers, no scratch).
@@ -41,18 +67,19 @@ struct EpiSplitSave {
   bool dens;
   float* img = nullptr;  // training: register image of this layer's output (field_layout.h), lane offset included
   unsigned* msk = nullptr;   // training: sign bits of the ReLU layer, 32 registers per word
+  const float* imgu = nullptr;   // the same image, wave-uniform (no lane offset), and the lane's byte offset
+  unsigned lane_bytes = 0;
   __device__ __forceinline__ void operator()(int t, int q, float x0, float x1) const {
     if (RELU) {
       x0 = relu_bits(x0);
       x1 = relu_bits(x1);
     }
-    if (img != nullptr) {
-      img[(16 * t + 2 * q) * 64] = x0;
-      img[(16 * t + 2 * q + 1) * 64] = x1;
+    if (img != nullptr) {      // always taken in the saving kernel; the run-time test keeps the piece a unit (see above)
+      image_pair_store(imgu + 16 * t * 64, lane_bytes, q, x0, x1);
       if (RELU) {
         unsigned& w = msk[(16 * t + 2 * q) >> 5];
-        w |= (x0 > 0.f ? 1u : 0u) << ((16 * t + 2 * q) & 31);
-        w |= (x1 > 0.f ? 1u : 0u) << ((16 * t + 2 * q + 1) & 31);
+        sign_bit_or(w, x0, (16 * t + 2 * q) & 31);
+        sign_bit_or(w, x1, (16 * t + 2 * q + 1) & 31);
       }
     }
     if (dens) *sigma = fmaf(x1, dw[16 * t + 2 * q + 1], fmaf(x0, dw[16 * t + 2 * q], *sigma));
@@ -70,14 +97,15 @@ struct EpiRgbSave {
   const float* rw;       // cst + kConstRgbW + h*64
   float* img = nullptr;  // training: image of the post-ReLU layer output, and its sign bits
   unsigned* msk = nullptr;
+  const float* imgu = nullptr;
+  unsigned lane_bytes = 0;
   __device__ __forceinline__ void operator()(int t, int q, float a0, float a1) const {
     const float x0 = relu_bits(a0), x1 = relu_bits(a1);
     if (img != nullptr) {
-      img[(16 * t + 2 * q) * 64] = x0;
-      img[(16 * t + 2 * q + 1) * 64] = x1;
+      image_pair_store(imgu + 16 * t * 64, lane_bytes, q, x0, x1);
       unsigned& w = msk[(16 * t + 2 * q) >> 5];
-      w |= (x0 > 0.f ? 1u : 0u) << ((16 * t + 2 * q) & 31);
-      w |= (x1 > 0.f ? 1u : 0u) << ((16 * t + 2 * q + 1) & 31);
+      sign_bit_or(w, x0, (16 * t + 2 * q) & 31);
+      sign_bit_or(w, x1, (16 * t + 2 * q + 1) & 31);
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -154,6 +182,8 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x3_kernel(const FieldArgs a)
   }
 
   if constexpr (SAVE) {
+  const float* const recu = a.save + ((long)blockIdx.x * 4 + wave_s) * kSaveTileFloats;      // wave-uniform save record
+  const unsigned lb = (unsigned)lane * 4u;
   frag act_h[16], act_l[16], nxt_h[16], nxt_l[16];
   float sigma = 0.f;
   const float* const dw = cst + kConstDensW + h * 128;
@@ -162,24 +192,24 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x3_kernel(const FieldArgs a)
 
   // ---- mlps.0: position encoding (4 k-steps) -> act
   layer_x3<P, 8, 4, 0>(c, cst + kConstBias8 + h * 128, pe_h, pe_l, pe_h, pe_l,
-                       Relu{act_h, act_l, &amax, &sigma, dw, false, true ? rec + save_h(1) * 64 : nullptr, msk});
+                       Relu{act_h, act_l, &amax, &sigma, dw, false, rec + save_h(1) * 64, msk, recu + save_h(1) * 64, lb});
   if (SAVE) flush_mask<4>(rec + save_mask(1) * 64, msk);
   // ---- mlps.1 .. mlps.7 in ping-pong pairs; mlps.5 (skip connection) also consumes the position encoding
   int l = 1;
 #pragma unroll 1
   for (int it = 0; it < 3; ++it) {
     layer_x3<P, 8, 16, 0>(c, cst + kConstBias8 + l * 256 + h * 128, act_h, act_l, pe_h, pe_l,
-                          Relu{nxt_h, nxt_l, &amax, &sigma, dw, false, true ? rec + (save_h(1) + 128 * l) * 64 : nullptr, msk});
+                          Relu{nxt_h, nxt_l, &amax, &sigma, dw, false, rec + (save_h(1) + 128 * l) * 64, msk, recu + (save_h(1) + 128 * l) * 64, lb});
     if (SAVE) flush_mask<4>(rec + (save_mask(1) + 4 * l) * 64, msk);
     ++l;
     layer_x3<P, 8, 16, 0>(c, cst + kConstBias8 + l * 256 + h * 128, nxt_h, nxt_l, pe_h, pe_l,
                           Relu{act_h, act_l, &amax, &sigma, dw, l == kDepth - 1,    // density from mlps.7 output
-                               true ? rec + (save_h(1) + 128 * l) * 64 : nullptr, msk});
+                               rec + (save_h(1) + 128 * l) * 64, msk, recu + (save_h(1) + 128 * l) * 64, lb});
     if (SAVE) flush_mask<4>(rec + (save_mask(1) + 4 * l) * 64, msk);
     ++l;
     if (it == 1) {
       layer_x3<P, 8, 16, 4>(c, cst + kConstBias8 + l * 256 + h * 128, act_h, act_l, pe_h, pe_l,
-                            Relu{nxt_h, nxt_l, &amax, &sigma, dw, false, true ? rec + (save_h(1) + 128 * l) * 64 : nullptr, msk});
+                            Relu{nxt_h, nxt_l, &amax, &sigma, dw, false, rec + (save_h(1) + 128 * l) * 64, msk, recu + (save_h(1) + 128 * l) * 64, lb});
       if (SAVE) flush_mask<4>(rec + (save_mask(1) + 4 * l) * 64, msk);
       ++l;
 #pragma unroll
@@ -195,10 +225,10 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x3_kernel(const FieldArgs a)
 
   // ---- rgb_feature_linear (no activation) -> nxt; rgb_feature_linears.0 on [feature, dirs] -> rgb_linear
   layer_x3<P, 8, 16, 0>(c, cst + kConstBias8 + 8 * 256 + h * 128, act_h, act_l, pe_h, pe_l,
-                        Lin{nxt_h, nxt_l, &amax, &sigma, dw, false, true ? rec + kSaveFeat * 64 : nullptr, msk});
+                        Lin{nxt_h, nxt_l, &amax, &sigma, dw, false, rec + kSaveFeat * 64, msk, recu + kSaveFeat * 64, lb});
   float rgb[3] = {0.f, 0.f, 0.f};
   layer_x3<P, 4, 16, 2>(c, cst + kConstBias4 + h * 64, nxt_h, nxt_l, qe_h, qe_l,
-                        EpiRgbSave{rgb, cst + kConstRgbW + h * 64, true ? rec + kSaveR1 * 64 : nullptr, msk});
+                        EpiRgbSave{rgb, cst + kConstRgbW + h * 64, rec + kSaveR1 * 64, msk, recu + kSaveR1 * 64, lb});
   if (SAVE) flush_mask<2>(rec + kSaveMaskR1 * 64, msk);
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -215,9 +245,9 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x3_kernel(const FieldArgs a)
 
   // ---- ins_feature_linear on the trunk output (no activation) -> nxt; ins_feature_linears.0 (ReLU) -> act[0..7]
   layer_x3<P, 8, 16, 0>(c, cst + kConstBias8 + 9 * 256 + h * 128, act_h, act_l, pe_h, pe_l,
-                        Lin{nxt_h, nxt_l, &amax, &sigma, dw, false, true ? rec + kSaveInsF * 64 : nullptr, msk});
+                        Lin{nxt_h, nxt_l, &amax, &sigma, dw, false, rec + kSaveInsF * 64, msk, recu + kSaveInsF * 64, lb});
   layer_x3<P, 4, 16, 0>(c, cst + kConstBias4 + 128 + h * 64, nxt_h, nxt_l, pe_h, pe_l,
-                        Relu{act_h, act_l, &amax, &sigma, dw, false, true ? rec + kSaveI1 * 64 : nullptr, msk});
+                        Relu{act_h, act_l, &amax, &sigma, dw, false, rec + kSaveI1 * 64, msk, recu + kSaveI1 * 64, lb});
   if (SAVE) flush_mask<2>(rec + kSaveMaskI1 * 64, msk);
   // ---- ins_linear: 128 -> ins_num + 1, T tiles, stored straight from the accumulators
   layer_x3<P, T, 8, 0>(c, cst + kConstBiasO + h * 64, act_h, act_l, pe_h, pe_l, EpiStore{out, a.ins_ch, h});

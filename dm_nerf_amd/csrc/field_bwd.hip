@@ -227,9 +227,9 @@ __global__ __launch_bounds__(256, 1) void field_wgrad_kernel(const WgArgs a) {
     const float* gsrc = a.grad + tile * a.grad_tile_floats + gm.g_reg * 64 + tid * 4;
     const float* xsrc = a.save + tile * kSaveTileFloats + gm.x_reg * 64 + tid * 4;
 #pragma unroll
-    for (int it = 0; it < OT; ++it) stg[it] = *reinterpret_cast<const f32x4*>(gsrc + it * 1024);
+    for (int it = 0; it < OT; ++it) stg[it] = record_load4(gsrc + it * 1024);
 #pragma unroll
-    for (int it = 0; it < KT; ++it) stg[OT + it] = *reinterpret_cast<const f32x4*>(xsrc + it * 1024);
+    for (int it = 0; it < KT; ++it) stg[OT + it] = record_load4(xsrc + it * 1024);
   };
   auto stage = [&](float* buf) {
 #pragma unroll
@@ -343,9 +343,9 @@ __global__ __launch_bounds__(256, 1) void field_wgrad_x3_kernel(const WgArgs a) 
     const float* gsrc = a.grad + tile * a.grad_tile_floats + gm.g_reg * 64 + tid * 4;
     const float* xsrc = a.save + tile * kSaveTileFloats + gm.x_reg * 64 + tid * 4;
 #pragma unroll
-    for (int it = 0; it < OT; ++it) stg[it] = *reinterpret_cast<const f32x4*>(gsrc + it * 1024);
+    for (int it = 0; it < OT; ++it) stg[it] = record_load4(gsrc + it * 1024);
 #pragma unroll
-    for (int it = 0; it < KT; ++it) stg[OT + it] = *reinterpret_cast<const f32x4*>(xsrc + it * 1024);
+    for (int it = 0; it < KT; ++it) stg[OT + it] = record_load4(xsrc + it * 1024);
   };
   auto stage = [&]() {
 #pragma unroll

@@ -46,8 +46,8 @@ struct EpiGrad {
       x0 = (w >> (i & 31)) & 1u ? x0 : 0.f;
       x1 = (w >> ((i + 1) & 31)) & 1u ? x1 : 0.f;
     }
-    img[i * 64] = x0;
-    img[(i + 1) * 64] = x1;
+    record_store(img + i * 64, x0);
+    record_store(img + (i + 1) * 64, x1);
     if (SPLIT) split_pair<P, true>(x0, x1, oh[2 * t + (q >> 2)], ol[2 * t + (q >> 2)], (2 * q) & 7);
   }
 };
@@ -85,14 +85,14 @@ __global__ __launch_bounds__(256, 1) void field_bwd_data_x3_kernel(const BwdX3Ar
     for (int i = 0; i < 16 * T; ++i) {
       const int ch = feat_of(i, 0) + 4 * h;
       gi[i] = (valid && ch < a.ins_ch) ? row[4 + (ch < a.ins_ch ? ch : 0)] : 0.f;
-      grec[(kGradHead + i) * 64] = gi[i];
+      record_store(grec + (kGradHead + i) * 64, gi[i]);
     }
 #pragma unroll
     for (int i = 0; i < 16 * T; i += 2) split_pair<P>(gi[i], gi[i + 1], gi_h[i >> 3], gi_l[i >> 3], i & 7);
-    grec[(kGradHead + 16 * T + 0) * 64] = h ? g_rgb[1] : g_rgb[0];
-    grec[(kGradHead + 16 * T + 1) * 64] = h ? g_sig : g_rgb[2];
+    record_store(grec + (kGradHead + 16 * T + 0) * 64, h ? g_rgb[1] : g_rgb[0]);
+    record_store(grec + (kGradHead + 16 * T + 1) * 64, h ? g_sig : g_rgb[2]);
 #pragma unroll
-    for (int i = 2; i < 16; ++i) grec[(kGradHead + 16 * T + i) * 64] = 0.f;
+    for (int i = 2; i < 16; ++i) record_store(grec + (kGradHead + 16 * T + i) * 64, 0.f);
   }
 
   frag act_h[16], act_l[16], nxt_h[16], nxt_l[16];
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_data_x3_kernel(const BwdX3Ar
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) x = fmaf(g_rgb[ch], cst[kConstRgbW + ch * 128 + h * 64 + i + e], x);
       v[e] = (msk[(i + e) >> 5] >> ((i + e) & 31)) & 1u ? x : 0.f;
-      grec[(kGradR1 + i + e) * 64] = v[e];
+      record_store(grec + (kGradR1 + i + e) * 64, v[e]);
     }
     split_pair<P>(v[0], v[1], nxt_h[i >> 3], nxt_l[i >> 3], i & 7);
   }

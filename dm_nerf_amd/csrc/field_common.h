@@ -29,8 +29,17 @@ struct FieldArgs {
   int sigma_only;        // x3 kernels: stop behind the trunk, raw = [0, 0, 0, sigma, 0...] (coarse pass of an image loop)
 };
 
+// Record stores are non-temporal (`global_store_dword ... nt`): a training step streams 12 GB of save record and 12 GB
+// of gradient record through each XCD's 4 MB L2, where plain stores evict the weight stream every workgroup re-reads
+// (saving forward 5.45 -> 4.45 ms, backward-data 4.85 -> 3.95 ms per step; sc1 / sc0 sc1 stores and 16-byte stores
+// at a quarter of the instruction count changed nothing: experiments/README.md).
+__device__ __forceinline__ void record_store(float* p, float v) { __builtin_nontemporal_store(v, p); }
 // register image access: register `reg` of this wave's tile record (wave-uniform base, one 256-byte row)
-__device__ __forceinline__ void image_store(float* rec, int reg, int lane, float v) { rec[reg * 64 + lane] = v; }
+__device__ __forceinline__ void image_store(float* rec, int reg, int lane, float v) { record_store(rec + reg * 64 + lane, v); }
+// 16 bytes of a record that is read once (the weight-gradient kernels): non-temporal as well
+__device__ __forceinline__ f32x4 record_load4(const float* p) {
+  return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+}
 __device__ __forceinline__ float image_load(const float* rec, int reg, int lane) { return rec[reg * 64 + lane]; }
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {

@@ -34,7 +34,7 @@ namespace {
 // in: two instructions instead of compare + select + shift + or.  Inline asm so that the forms survive the optimiser.
 template <int ROW>
 __device__ __forceinline__ void image_row_store(const float* tile_rows, unsigned lane_bytes, float x) {
-  asm volatile("global_store_dword %0, %1, %2 offset:%3" : : "v"(lane_bytes), "v"(x), "s"(tile_rows), "n"(ROW * 256));
+  asm volatile("global_store_dword %0, %1, %2 offset:%3 nt" : : "v"(lane_bytes), "v"(x), "s"(tile_rows), "n"(ROW * 256));
 }
 __device__ __forceinline__ void image_pair_store(const float* tile_rows, unsigned lane_bytes, int q, float x0, float x1) {
   switch (q) {      // q is a compile-time constant where this is inlined (unrolled epilogue pieces)
@@ -131,7 +131,7 @@ template <int N>
 __device__ __forceinline__ void flush_mask(float* dst, unsigned* msk) {
 #pragma unroll
   for (int w = 0; w < N; ++w) {
-    dst[w * 64] = __uint_as_float(msk[w]);
+    record_store(dst + w * 64, __uint_as_float(msk[w]));
     msk[w] = 0u;
   }
 }
@@ -168,9 +168,9 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x3_kernel(const FieldArgs a)
     point_encodings(a, mc, h, pe, qe);
     if (SAVE) {
 #pragma unroll
-      for (int j = 0; j < 32; ++j) rec[(kSavePe + j) * 64] = pe[j];
+      for (int j = 0; j < 32; ++j) record_store(rec + (kSavePe + j) * 64, pe[j]);
 #pragma unroll
-      for (int j = 0; j < 16; ++j) rec[(kSaveQe + j) * 64] = qe[j];
+      for (int j = 0; j < 16; ++j) record_store(rec + (kSaveQe + j) * 64, qe[j]);
     }
 #pragma unroll
     for (int j = 0; j < 32; j += 2) {

@@ -62,7 +62,257 @@ __global__ void ins_stats_bwd_kernel(const float* pred, const long* cls, long N,
   g_pred[e] = g1 / (x + 1e-8f) - g0 / (1.f - x + 1e-8f) + gt;
 }
 
+// ---- the whole loss head in five launches (evaluator.py:19-74 without its ~100 small tensor operations) -------
+// labels -> classes: histogram of the labels in LDS (integer atomics), the labels present in increasing order get the
+// class indices 0 .. V-1 (what torch.unique's inverse gives), count[v] = rays of class v.  meta = {V, error flag}.
+constexpr int kMaxLabel = 1024;
+
+__global__ __launch_bounds__(1024) void ins_label_prep_kernel(const long* labels, long N, int Vmax, long* classes,
+                                                              float* count, int* meta) {
+  __shared__ int hist[kMaxLabel];
+  __shared__ int slot[kMaxLabel];
+  __shared__ int bad;
+  const int tid = threadIdx.x;
+  hist[tid] = 0;
+  if (tid == 0) bad = 0;
+  __syncthreads();
+  for (long i = tid; i < N; i += 1024) {
+    const long l = labels[i];
+    if (l < 0 || l >= kMaxLabel) bad = 1; else atomicAdd(&hist[l], 1);
+  }
+  __syncthreads();
+  // exclusive prefix count of the non-empty bins (Hillis-Steele over 1024 flags)
+  const int mine = hist[tid] > 0 ? 1 : 0;
+  slot[tid] = mine;
+  __syncthreads();
+  for (int d = 1; d < kMaxLabel; d <<= 1) {
+    const int add = tid >= d ? slot[tid - d] : 0;
+    __syncthreads();
+    slot[tid] += add;
+    __syncthreads();
+  }
+  const int V = slot[kMaxLabel - 1];
+  const int my_slot = slot[tid] - mine;
+  __syncthreads();
+  slot[tid] = mine ? my_slot : -1;
+  if (mine && my_slot < Vmax) count[my_slot] = (float)hist[tid];
+  if (tid >= V && tid < Vmax) count[tid] = 0.f;
+  __syncthreads();
+  const bool fail = bad != 0 || V > Vmax;
+  if (tid == 0) {
+    meta[0] = V;
+    meta[1] = fail ? 1 : 0;
+  }
+  for (long i = tid; i < N; i += 1024) {
+    const long l = labels[i];
+    classes[i] = (fail || l < 0 || l >= kMaxLabel) ? 0 : slot[l];
+  }
+}
+
+// the statistics without sorting the rays: workgroup v walks ALL class indices and adds up the rows of its own class, in
+// ray order (wave w owns the w-th quarter of the rays; the four partial sums are added in wave order): deterministic
+__global__ __launch_bounds__(256) void ins_stats_scan_kernel(const float* pred, const long* cls, long N, int K,
+                                                             float* stats /* [3][V][K] */, int V) {
+  __shared__ double part[4][3][kMaxCols];
+  const int v = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long per = ((N + 255) / 256) * 64;          // rays per wave, whole groups of 64
+  const long begin = wave * per, end = begin + per < N ? begin + per : N;
+  double s1[2] = {0.0, 0.0}, s0[2] = {0.0, 0.0}, tp[2] = {0.0, 0.0};
+  for (long i0 = begin; i0 < end; i0 += 64) {
+    const long i = i0 + lane;
+    unsigned long long hit = __ballot(i < end && cls[i] == v);
+    while (hit) {
+      const int j = __ffsll((long long)hit) - 1;
+      hit &= hit - 1;
+      const float* row = pred + (i0 + j) * K;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int p = lane + 64 * c;
+        if (p < K) {
+          const float x = row[p];
+          s1[c] += (double)logf(x + 1e-8f);
+          s0[c] += (double)logf(1.f - x + 1e-8f);
+          tp[c] += (double)x;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    part[wave][0][lane + 64 * c] = s1[c];
+    part[wave][1][lane + 64 * c] = s0[c];
+    part[wave][2][lane + 64 * c] = tp[c];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 3 * K; e += 256) {
+    const int q = e / K, p = e - q * K;
+    stats[((long)q * V + v) * K + p] = (float)(part[0][q][p] + part[1][q][p] + part[2][q][p] + part[3][q][p]);
+  }
+}
+
+// cost matrices (evaluator.py:60-70) from the statistics; host_blob = {V, flag, cost_ce + cost_siou [Vmax][K]} is what
+// the host's Hungarian step reads back in one copy
+__global__ __launch_bounds__(256) void ins_cost_kernel(const float* stats, const float* count, const int* meta, long N,
+                                                       int K, int Vmax, float* cost /* [2][Vmax][K] */, float* colsum /* [2][K] */,
+                                                       float* host_blob) {
+  __shared__ float s0sum[kMaxCols], tpsum[kMaxCols];
+  const int V = meta[0];
+  const float* s1 = stats;
+  const float* s0 = stats + (long)Vmax * K;
+  const float* tp = stats + 2L * Vmax * K;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    float a = 0.f, b = 0.f;
+    for (int v = 0; v < V; ++v) {
+      a += s0[v * K + k];
+      b += tp[v * K + k];
+    }
+    s0sum[k] = a;
+    tpsum[k] = b;
+    colsum[k] = a;
+    colsum[K + k] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    host_blob[0] = (float)V;
+    host_blob[1] = (float)meta[1];
+  }
+  const float n = (float)N;
+  for (int e = threadIdx.x; e < Vmax * K; e += 256) {
+    const int v = e / K, k = e - v * K;
+    float ce = 0.f, siou = 0.f;
+    if (v < V) {
+      ce = -(s1[e] + (s0sum[k] - s0[e])) / n;                         // :60
+      const float t = tp[e];
+      const float fp = tpsum[k] - t, fn = count[v] - t;               // :63-65
+      siou = 1.0f - t / (t + fp + fn + 1e-6f);                        // :66-67
+    }
+    cost[e] = ce;
+    cost[(long)Vmax * K + e] = siou;
+    host_blob[2 + e] = ce + siou;
+  }
+}
+
+// loss terms for a matching: col_of[v] = column matched to class v (v < V), class_of[k] = class matched to column k or -1
+// out = {valid_ce + invalid_ce + valid_siou, valid_ce, invalid_ce, valid_siou} (evaluator.py:27-37)
+__global__ __launch_bounds__(64) void ins_loss_kernel(const float* cost, const float* colsum, const int* col_of,
+                                                      const int* class_of, const int* meta, long N, int K, int Vmax,
+                                                      float* out) {
+  const int V = meta[0];
+  const int lane = threadIdx.x;
+  float ce = 0.f, siou = 0.f, inv = 0.f;
+  int unmatched = 0;
+  for (int v = lane; v < V; v += 64) {
+    ce += cost[v * K + col_of[v]];
+    siou += cost[(long)Vmax * K + v * K + col_of[v]];
+  }
+  for (int k = lane; k < K; k += 64)
+    if (class_of[k] < 0) {
+      inv += colsum[K + k];
+      ++unmatched;
+    }
+  for (int d = 32; d >= 1; d >>= 1) {
+    ce += __shfl_xor(ce, d);
+    siou += __shfl_xor(siou, d);
+    inv += __shfl_xor(inv, d);
+    unmatched += __shfl_xor(unmatched, d);
+  }
+  if (lane == 0) {
+    const float valid_ce = ce / (float)V, valid_siou = siou / (float)V;
+    const float invalid_ce = unmatched ? inv / ((float)N * (float)unmatched) : 0.f;
+    out[0] = valid_ce + invalid_ce + valid_siou;
+    out[1] = valid_ce;
+    out[2] = invalid_ce;
+    out[3] = valid_siou;
+  }
+}
+
+// d out / d stats for upstream gradients g[4] (null = 0) of the four outputs
+__global__ __launch_bounds__(256) void ins_loss_bwd_kernel(const float* stats, const float* count, const float* colsum,
+                                                           const int* class_of, const int* meta, long N, int K, int Vmax,
+                                                           const float* g_total, const float* g_ce, const float* g_inv,
+                                                           const float* g_siou, float* g_stats) {
+  __shared__ int n_unmatched;
+  const int V = meta[0];
+  if (threadIdx.x == 0) {
+    int u = 0;
+    for (int k = 0; k < K; ++k) u += class_of[k] < 0;
+    n_unmatched = u;
+  }
+  __syncthreads();
+  const float gt = g_total ? *g_total : 0.f;
+  const float a = gt + (g_ce ? *g_ce : 0.f), b = gt + (g_inv ? *g_inv : 0.f), s = gt + (g_siou ? *g_siou : 0.f);
+  const float n = (float)N, fv = (float)V;
+  const float* tp = stats + 2L * Vmax * K;
+  for (int e = threadIdx.x; e < Vmax * K; e += 256) {
+    const int v = e / K, k = e - v * K;
+    float g1 = 0.f, g0 = 0.f, gtp = 0.f;
+    if (v < V) {
+      const int vk = class_of[k];
+      if (vk >= 0) {
+        if (v == vk) g1 = -a / (n * fv); else g0 = -a / (n * fv);
+        const float t = tp[vk * K + k];
+        const float D = colsum[K + k] - t + count[vk] + 1e-6f;      // t + fp + fn + 1e-6
+        gtp = (v == vk ? -1.f / D : t / (D * D)) * s / fv;
+      } else {
+        gtp = b / (n * (float)n_unmatched);
+      }
+    }
+    g_stats[e] = g1;
+    g_stats[(long)Vmax * K + e] = g0;
+    g_stats[2L * Vmax * K + e] = gtp;
+  }
+}
+
 }  // namespace
+
+extern "C" int dmn_ins_label_prep(const long* labels, long n_rays, int max_classes, long* classes, float* count,
+                                  int* meta, void* stream) {
+  if (n_rays <= 0 || max_classes <= 0 || max_classes > kMaxCols) return DMN_ERR_BAD_ARG;
+  if (!labels || !classes || !count || !meta) return DMN_ERR_BAD_ARG;
+  hipLaunchKernelGGL(ins_label_prep_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, labels, n_rays, max_classes,
+                     classes, count, meta);
+  return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
+}
+
+extern "C" int dmn_ins_stats_scan(const float* pred, const long* classes, long n_rays, int n_cols, int n_classes,
+                                  float* stats, void* stream) {
+  if (n_rays < 0 || n_cols <= 0 || n_classes <= 0) return DMN_ERR_BAD_ARG;
+  if (n_cols > kMaxCols) return DMN_ERR_UNSUPPORTED;
+  if (!pred || !classes || !stats) return DMN_ERR_BAD_ARG;
+  hipLaunchKernelGGL(ins_stats_scan_kernel, dim3(n_classes), dim3(256), 0, (hipStream_t)stream, pred, classes, n_rays,
+                     n_cols, stats, n_classes);
+  return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
+}
+
+extern "C" int dmn_ins_cost(const float* stats, const float* count, const int* meta, long n_rays, int n_cols,
+                            int max_classes, float* cost, float* colsum, float* host_blob, void* stream) {
+  if (n_rays <= 0 || n_cols <= 0 || n_cols > kMaxCols || max_classes <= 0) return DMN_ERR_BAD_ARG;
+  if (!stats || !count || !meta || !cost || !colsum || !host_blob) return DMN_ERR_BAD_ARG;
+  hipLaunchKernelGGL(ins_cost_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stats, count, meta, n_rays, n_cols,
+                     max_classes, cost, colsum, host_blob);
+  return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
+}
+
+extern "C" int dmn_ins_loss(const float* cost, const float* colsum, const int* col_of, const int* class_of,
+                            const int* meta, long n_rays, int n_cols, int max_classes, float* out4, void* stream) {
+  if (n_rays <= 0 || n_cols <= 0 || n_cols > kMaxCols || max_classes <= 0) return DMN_ERR_BAD_ARG;
+  if (!cost || !colsum || !col_of || !class_of || !meta || !out4) return DMN_ERR_BAD_ARG;
+  hipLaunchKernelGGL(ins_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, cost, colsum, col_of, class_of, meta,
+                     n_rays, n_cols, max_classes, out4);
+  return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
+}
+
+extern "C" int dmn_ins_loss_bwd(const float* stats, const float* count, const float* colsum, const int* class_of,
+                                const int* meta, long n_rays, int n_cols, int max_classes, const float* g_total,
+                                const float* g_ce, const float* g_inv, const float* g_siou, float* g_stats,
+                                void* stream) {
+  if (n_rays <= 0 || n_cols <= 0 || n_cols > kMaxCols || max_classes <= 0) return DMN_ERR_BAD_ARG;
+  if (!stats || !count || !colsum || !class_of || !meta || !g_stats) return DMN_ERR_BAD_ARG;
+  hipLaunchKernelGGL(ins_loss_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stats, count, colsum, class_of,
+                     meta, n_rays, n_cols, max_classes, g_total, g_ce, g_inv, g_siou, g_stats);
+  return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
+}
 
 extern "C" int dmn_ins_stats_fwd(const float* pred, const long* order, const long* segments, long n_rays, int n_cols,
                                  int n_classes, float* stats, void* stream) {

@@ -78,6 +78,7 @@ class DM_NeRF(nn.Module):
         self.precision = "fp32"          # arithmetic of forward(); the render path passes its own
         self._blobs = {}                 # precision -> (key, blob)
         self._indices = {}               # (flavour, device) -> gather table
+        self._flat = None                # (key, parameters as one flat vector) of the last blob packed
         self._grad_flat = None           # persistent flat gradient buffer (parallel.GradBucket hands out slices)
 
     # ---- packed weights -------------------------------------------------------------------
@@ -104,8 +105,12 @@ class DM_NeRF(nn.Module):
             make = {"fp32": ops.pack_index, "bwd": ops.bwd_pack_index, "bwd_x3": ops.bwd_pack_index_x3,
                     "x3": ops.pack_index_x3}[flavour]
             index = self._indices[(flavour, dev)] = make(self.ins_num, dev)
-        with torch.no_grad():
-            flat = torch.cat([p.detach().reshape(-1).float() for p in params])
+        if self._flat is not None and self._flat[0] == key:      # the backward's blob follows the forward's: one gather
+            flat = self._flat[1]
+        else:
+            with torch.no_grad():
+                flat = torch.cat([p.detach().reshape(-1).float() for p in params])
+            self._flat = (key, flat)
         if flavour == "x3":
             blob = ops.pack_blob_x3(flat, index, self.ins_num, precision)
         elif flavour == "bwd_x3":
@@ -136,6 +141,7 @@ class DM_NeRF(nn.Module):
     def invalidate_blobs(self) -> None:
         """Drop the packed-weight cache (needed only after parameter writes through ``.data``, see ``blob``)."""
         self._blobs.clear()
+        self._flat = None
 
     def wgrad_index(self) -> torch.Tensor:
         """Scatter table of the weight-gradient kernel (ops.field_backward) on the parameters' device."""

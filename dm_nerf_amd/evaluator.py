@@ -43,7 +43,78 @@ class _ClassStatsFn(torch.autograd.Function):
         return g_pred, None, None
 
 
-def ins_criterion(pred_ins: torch.Tensor, gt_labels: torch.Tensor, ins_num: int, reduce=None):
+# classes / counts of the last labels tensor seen (the coarse and the fine call of a step share their labels)
+_LABEL_PREP = {}
+
+
+def _label_prep(labels: torch.Tensor, ins_num: int):
+    key = (labels.data_ptr(), labels._version, labels.shape[0], ins_num, labels.device)
+    hit = _LABEL_PREP.get("last")
+    if hit is not None and hit[0] == key and hit[1] is labels:
+        return hit[2]
+    n = labels.shape[0]
+    classes = torch.empty(n, dtype=torch.int64, device=labels.device)
+    count = torch.empty(ins_num, dtype=torch.float32, device=labels.device)
+    meta = torch.empty(2, dtype=torch.int32, device=labels.device)
+    check(load().dmn_ins_label_prep(ptr(labels), n, ins_num, ptr(classes), ptr(count), ptr(meta), current_stream()),
+          "dmn_ins_label_prep")
+    _LABEL_PREP["last"] = (key, labels, (classes, count, meta))
+    return classes, count, meta
+
+
+class _InsCriterionFn(torch.autograd.Function):
+    """The whole loss head on the device in five launches, one read-back (cost matrix) and one upload (the matching):
+    pred [N, K], labels [N] -> [sum, valid_ce, invalid_ce, valid_siou].  Returns None for inputs the fused kernels do
+    not take (labels outside [0, 1024), more labels than columns): the caller falls back to the tensor-op path."""
+
+    @staticmethod
+    def forward(ctx, pred, labels, ins_num):
+        from scipy.optimize import linear_sum_assignment
+        lib = load()
+        pred = ops._dev(pred, "pred_ins").contiguous()
+        n, k = pred.shape
+        dev, st = pred.device, current_stream()
+        classes, count, meta = _label_prep(labels, ins_num)
+        stats = torch.empty(3, ins_num, k, dtype=torch.float32, device=dev)
+        check(lib.dmn_ins_stats_scan(ptr(pred), ptr(classes), n, k, ins_num, ptr(stats), st), "dmn_ins_stats_scan")
+        cost = torch.empty(2, ins_num, k, dtype=torch.float32, device=dev)
+        colsum = torch.empty(2, k, dtype=torch.float32, device=dev)
+        blob = torch.empty(2 + ins_num * k, dtype=torch.float32, device=dev)
+        check(lib.dmn_ins_cost(ptr(stats), ptr(count), ptr(meta), n, k, ins_num, ptr(cost), ptr(colsum), ptr(blob), st),
+              "dmn_ins_cost")
+        host = blob.cpu().numpy()                                                     # the step's one wait for the device
+        v = int(host[0])
+        if host[1] != 0.0 or v == 0:
+            return None
+        rows, cols = linear_sum_assignment(host[2:].reshape(ins_num, k)[:v])           # reorder(), :42-52
+        match = np.full(ins_num + k, -1, dtype=np.int32)
+        match[rows] = cols                                                            # col_of [ins_num]
+        match[ins_num + cols] = rows                                                  # class_of [k]
+        match_t = torch.from_numpy(match).to(dev)
+        out = torch.empty(4, dtype=torch.float32, device=dev)
+        check(lib.dmn_ins_loss(ptr(cost), ptr(colsum), ptr(match_t), ptr(match_t) + 4 * ins_num, ptr(meta), n, k,
+                               ins_num, ptr(out), st), "dmn_ins_loss")
+        ctx.save_for_backward(pred, classes, stats, count, colsum, match_t, meta)
+        ctx.ins_num = ins_num
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        pred, classes, stats, count, colsum, match_t, meta = ctx.saved_tensors
+        lib, st = load(), current_stream()
+        n, k = pred.shape
+        g = g_out.float().contiguous()                 # [4]: gradients of sum, valid_ce, invalid_ce, valid_siou
+        g_stats = torch.empty_like(stats)
+        check(lib.dmn_ins_loss_bwd(ptr(stats), ptr(count), ptr(colsum), ptr(match_t) + 4 * ctx.ins_num, ptr(meta), n, k,
+                                   ctx.ins_num, ptr(g), ptr(g) + 4, ptr(g) + 8, ptr(g) + 12, ptr(g_stats), st),
+              "dmn_ins_loss_bwd")
+        g_pred = torch.empty_like(pred)
+        check(lib.dmn_ins_stats_bwd(ptr(pred), ptr(classes), n, k, ctx.ins_num, ptr(g_stats), ptr(g_pred), st),
+              "dmn_ins_stats_bwd")
+        return g_pred, None, None
+
+
+def ins_criterion(pred_ins: torch.Tensor, gt_labels: torch.Tensor, ins_num: int, reduce=None, fused: bool = True):
     """``(ins_loss_sum, valid_ce, invalid_ce, valid_siou)`` of networks/evaluator.py:19-38 for ``pred_ins [N, ins_num]``
     (the rendered, sigmoided instance map) and integer ``gt_labels [N]``.  All four are 0-dim tensors
     (the reference's ``invalid_ce`` is ``tensor([0])`` when every column is matched).
@@ -51,13 +122,22 @@ def ins_criterion(pred_ins: torch.Tensor, gt_labels: torch.Tensor, ins_num: int,
     ``reduce`` (ray-sharded training, ``parallel.ShardReducer``): called as ``reduce(tag, tensor)`` on the label-presence
     mask, the class counts, the ray count and the ``[3, V, K]`` class statistics; it returns their sums over all shards.
     Matching and normalisation then see the whole batch (evaluator.py:21,60-70), every rank computes the same loss
-    value, and its backward reaches the rank's own rays only -- so gradients must be SUMMED over ranks."""
+    value, and its backward reaches the rank's own rays only -- so gradients must be SUMMED over ranks.
+
+    Without ``reduce`` the loss head runs as fused kernels (``csrc/ins_stats.hip``: label classes, class statistics,
+    cost matrices, loss terms and their gradient), with the Hungarian step on the host in between."""
     from scipy.optimize import linear_sum_assignment
 
     if pred_ins.dim() != 2 or pred_ins.shape[1] != ins_num or gt_labels.shape[0] != pred_ins.shape[0]:
         raise ValueError("pred_ins must be [N, ins_num] and gt_labels [N]")
     n = pred_ins.shape[0]
-    labels = gt_labels.long()
+    labels = gt_labels if gt_labels.dtype == torch.int64 else gt_labels.long()
+    if fused and reduce is None and n > 0 and ins_num <= 128 and pred_ins.is_cuda:
+        # five launches instead of ~100 tensor operations (the host is the bottleneck of this part of a training step);
+        # ``fused=False`` is the same arithmetic written with tensor operations (and the only form under ``reduce``)
+        got = _InsCriterionFn.apply(pred_ins, labels.to(pred_ins.device).contiguous(), ins_num)
+        if got is not None:
+            return got[0], got[1], got[2], got[3]
     if reduce is None:
         valid, classes = torch.unique(labels, return_inverse=True)                    # :21, :25 (sorted labels)
         v = int(valid.numel())                                                        # :24

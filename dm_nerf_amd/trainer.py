@@ -12,6 +12,7 @@ scipy Hungarian on the host as in the reference), both with the reference's sign
 functions plug in just as well.  Without them the step optimises the two colour terms only."""
 from __future__ import annotations
 
+import math
 from typing import Callable, Dict, Optional, Tuple
 
 import torch
@@ -61,8 +62,11 @@ def train_step(i: int, batch_rays, target_rgb, nerf, z_vals_coarse, optimizer, l
     optimizer.step()
     for group in optimizer.param_groups:                                            # applied after the step, :68-72
         group["lr"] = decayed_lrate(i, lrate, lrate_decay)
-    return {k: float(v.detach()) for k, v in terms.items()} | {"total": float(total.detach()),
-                                                               "psnr_fine": float(-10.0 * torch.log10(mse_f.detach()))}
+    names = list(terms) + ["total"]                                 # one read-back for all of them
+    vals = torch.stack([v.detach().float().reshape(()) for v in terms.values()] + [total.detach().float()]).tolist()
+    report = dict(zip(names, vals))
+    report["psnr_fine"] = -10.0 * math.log10(report["rgb_fine"]) if report["rgb_fine"] > 0 else float("inf")
+    return report
 
 
 def checkpoint_dict(i: int, model_coarse, model_fine, optimizer) -> dict:

@@ -939,6 +939,34 @@ def test_ins_criterion_matches_reference_golden(golden):
         np.testing.assert_allclose(got[2:], want[2:], rtol=2e-5, atol=2e-6 * np.abs(want[2:]).max())   # unsaturated rows
 
 
+def test_fused_loss_head_equals_the_tensor_operation_form():
+    """dm.ins_criterion runs as five kernels around the host's Hungarian step; ``fused=False`` is the same arithmetic in
+    tensor operations (the form pinned by G11 since round 1).  All four terms and the gradient of EACH of them (G11 holds
+    the gradient of the total only), for every criterion case; labels the fused kernels do not take fall back."""
+    for tag, (n, ins_num, present, seed) in cases.CRITERION_CASES.items():
+        pred, labels = cases.criterion_case(n, ins_num, present, seed)
+        lab = torch.from_numpy(labels).to(DEV)
+        for term in range(4):
+            grads, vals = [], []
+            for fused in (True, False):
+                p = G(pred).requires_grad_(True)
+                out = dm.ins_criterion(p, lab, ins_num, fused=fused)
+                vals.append([float(o.detach()) for o in out])
+                if out[term].requires_grad:
+                    out[term].backward()
+                    grads.append(H(p.grad))
+            for a, b in zip(*vals):
+                assert abs(a - b) <= 2e-6 * max(abs(b), 1e-3), (tag, vals)
+            if len(grads) == 2:
+                np.testing.assert_allclose(grads[0], grads[1], rtol=2e-5, atol=2e-6 * np.abs(grads[1]).max(), err_msg=f"{tag} term {term}")
+    # labels beyond the fused kernels' table (>= 1024): same values through the fallback
+    pred, labels = cases.criterion_case(*cases.CRITERION_CASES[next(iter(cases.CRITERION_CASES))])
+    far = torch.from_numpy(labels).to(DEV) * 1000
+    a = dm.ins_criterion(G(pred), far, cases.CRITERION_CASES[next(iter(cases.CRITERION_CASES))][1])
+    b = dm.ins_criterion(G(pred), far, cases.CRITERION_CASES[next(iter(cases.CRITERION_CASES))][1], fused=False)
+    assert [float(x) for x in a] == [float(x) for x in b]
+
+
 # ---- ray-sharded training is batch-exact (SURVEY.md section 8e) ----------------------------------------------
 class _TwoShardReducer:
     """Single-process stand-in for parallel.ShardReducer: pass 1 records what a shard would contribute, pass 2 returns

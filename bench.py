@@ -127,13 +127,12 @@ def training_leg(nerf, K, pose, device, n_rays: int = 4096, steps: int = 4):
         wg_bytes = points * 212 * 128
         t_wg = entry["kernels_ms_per_step"]["field_bwd_weights"] * 1e-3
         entry["roofline_weight_gradients"] = {
-            "kernel": "field_wgrad_x3_kernel<8,8,2,2> + the small GEMM classes + field_wgrad_reduce_kernel (one event "
+            "kernel": "field_wgrad_ring_kernel (nine 256x256 GEMMs) + the small GEMM classes + field_wgrad_reduce_kernel (one event "
                       "around dmn_field_bwd_weights, both networks)", "bound": "hbm", "achieved": wg_bytes / t_wg / 1e9,
             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": wg_bytes / t_wg / 1e9 / PEAK_HBM_GBS,
             "algorithmic_bytes_per_step": wg_bytes,
-            "traffic": 29.1e9 if INS_NUM == 13 and n_rays == 4096 else None,      # 28.46 GB fetched + 0.64 GB of partials written
-            "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per step, profiles/r01e_train_hbm_traffic.txt "
-                              "(kernels unchanged since)"}
+            "traffic": 29.8e9 if INS_NUM == 13 and n_rays == 4096 else None,      # 29.1 GB fetched + 0.65 GB of partials written
+            "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per step, profiles/r02e_train_hbm_traffic.txt"}
         result[f"forward_{prec}"] = entry
     coarse.load_state_dict(state[0]); fine.load_state_dict(state[1])
     coarse.eval(); fine.eval()

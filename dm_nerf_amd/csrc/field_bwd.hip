@@ -428,6 +428,187 @@ __global__ __launch_bounds__(256, 1) void field_wgrad_x3_kernel(const WgArgs a) 
   }
 }
 
+// The nine 256 x 256 GEMMs again, fed by an LDS-DMA ring instead of staging registers and LDS planes.
+// field_wgrad_x3_kernel has one 64 KB tile in flight per CU, and only while it multiplies (the registers of tile t+1
+// are free for the fetch only after tile t is converted): 4.2 us per tile of which 2.1 us are waiting for HBM; and its
+// conversion pass (registers -> bf16 hi / lo planes in LDS, two barriers) runs with the matrix pipe idle.  Here the
+// 32-point tile is cut into two 16-point halves (one k-step each); a half arrives as raw fp32 rows (64 bytes per row) in
+// one of four 32 KB ring slots by global_load_lds, three halves are in flight while one is multiplied, and every wave
+// converts its own operand fragments from the raw rows (two 16-byte LDS reads per fragment, the same number the planes
+// took) in the shadow of its MFMAs (hand-placed: see the loop): no staging registers, no planes, ONE barrier per half.  The G and X fragments a
+// wave needs are converted by two waves each; that VALU work hides behind the 48 MFMAs of a half.
+// Bank conflicts: rows of 64 bytes would put rows l, l+4, l+8, l+12 of a 16-byte read on the same banks; the ring holds
+// piece c of row r at position c ^ ((r >> 2) & 3) instead (the DMA lane fetches the piece that belongs in ITS slot).
+// Past the end of the slice the ring keeps fetching the last tile, so that the wait count is the same in every iteration.
+__global__ __launch_bounds__(256, 1) void field_wgrad_ring_kernel(const WgArgs a) {
+  constexpr int ROWS = 512;                 // 256 G rows, then 256 X rows
+  constexpr int HB = ROWS * 64;             // bytes of a half: 16 points x 4 B per row
+  constexpr int RING = 4;
+  constexpr int OTW = 4, KTW = 4;           // 2 x 2 waves
+  __shared__ __attribute__((aligned(16))) char lds[RING * HB];      // 128 KB
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, l = lane & 31, kh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const WGemm gm = a.gemm[a.list[blockIdx.y]];
+  const long per = (a.n_tiles + a.splits - 1) / a.splits;
+  const long t0 = (long)blockIdx.x * per;
+  const long t1 = t0 + per < a.n_tiles ? t0 + per : a.n_tiles;
+  float* const part = a.partial + (long)blockIdx.x * a.slice_len - a.elem_base;
+
+  f32x16 acc[OTW * KTW];
+#pragma unroll
+  for (int n = 0; n < OTW * KTW; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+  float bsum[OTW] = {0.f, 0.f, 0.f, 0.f};
+
+  // DMA instruction n (0..7) of this wave fills ring positions n*256 + wave*64 + lane: row n*64 + wave*16 + lane/4
+  // (n < 4: G rows, else X rows), position lane%4 of the row = piece (lane%4) ^ ((row >> 2) & 3), and (row >> 2) & 3
+  // = (lane >> 4) & 3 for every n and wave
+  const unsigned lane_bytes = (unsigned)(lane >> 2) * 128u + (unsigned)((lane & 3) ^ ((lane >> 4) & 3)) * 16u;
+  auto issue = [&](long hidx) {
+    long tile = t0 + (hidx >> 1);
+    tile = tile < t1 ? tile : t1 - 1;
+    const int hh = (int)(hidx & 1);
+    const char* g = reinterpret_cast<const char*>(a.grad + tile * a.grad_tile_floats + gm.g_reg * 64) + wave * 16 * 128 + hh * 64;
+    const char* x = reinterpret_cast<const char*>(a.save + tile * kSaveTileFloats + gm.x_reg * 64) + wave * 16 * 128 + hh * 64;
+    char* dst = lds + (int)(hidx & (RING - 1)) * HB + wave * 1024;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) glds16_u(g + n * 8192, lane_bytes, dst + n * 4096);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) glds16_u(x + n * 8192, lane_bytes, dst + (4 + n) * 4096);
+  };
+  // operand fragment of one row: points 8*kh .. 8*kh+7 of the half = pieces 2*kh, 2*kh+1, split into bf16 hi / lo
+  const int sw = (l >> 2) & 3;
+  const int off0 = ((2 * kh) ^ sw) * 16, off1 = ((2 * kh + 1) ^ sw) * 16;
+  struct Raw { f32x4 v0, v1; };
+  auto fetch_row = [&](const char* row) -> Raw {
+    return Raw{*reinterpret_cast<const f32x4*>(row + off0), *reinterpret_cast<const f32x4*>(row + off1)};
+  };
+  auto split = [&](const Raw& r, bf16x8& hi, bf16x8& lo) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const bf16x4 h0 = __builtin_convertvector(r.v0, bf16x4), h1 = __builtin_convertvector(r.v1, bf16x4);
+    const u32x2 w0 = __builtin_bit_cast(u32x2, h0), w1 = __builtin_bit_cast(u32x2, h1);
+    const f32x4 b0 = {__builtin_bit_cast(float, w0.x << 16), __builtin_bit_cast(float, w0.x & 0xffff0000u),
+                      __builtin_bit_cast(float, w0.y << 16), __builtin_bit_cast(float, w0.y & 0xffff0000u)};
+    const f32x4 b1 = {__builtin_bit_cast(float, w1.x << 16), __builtin_bit_cast(float, w1.x & 0xffff0000u),
+                      __builtin_bit_cast(float, w1.y << 16), __builtin_bit_cast(float, w1.y & 0xffff0000u)};
+    const bf16x4 l0 = __builtin_convertvector(r.v0 - b0, bf16x4), l1 = __builtin_convertvector(r.v1 - b1, bf16x4);
+    hi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+    lo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  auto row_sum = [](const Raw& r) { return ((r.v0.x + r.v0.y) + (r.v0.z + r.v0.w)) + ((r.v1.x + r.v1.y) + (r.v1.z + r.v1.w)); };
+  auto triple = [&](int i, int j, const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl) {
+    f32x16 c = acc[i * KTW + j];
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+    acc[i * KTW + j] = c;
+  };
+#define DMN_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+  if (t0 < t1) {
+    const long H = 2 * (t1 - t0);
+    issue(0);
+    issue(1);
+    issue(2);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // half 0
+    __syncthreads();
+    // A0 / B0 of the half about to be multiplied are converted at the end of the half before (here: up front)
+    bf16x8 ah[OTW], al[OTW], bh[2], bl[2], nah, nal, nbh, nbl;
+    {
+      const Raw ra = fetch_row(lds + (wr * OTW * 32 + l) * 64), rb = fetch_row(lds + (256 + wc * KTW * 32 + l) * 64);
+      split(ra, nah, nal);
+      split(rb, nbh, nbl);
+      bsum[0] += row_sum(ra);
+    }
+    for (long h = 0; h < H; ++h) {
+      const char* pa = lds + (int)(h & (RING - 1)) * HB + (wr * OTW * 32 + l) * 64;
+      const char* pb = lds + (int)(h & (RING - 1)) * HB + (256 + wc * KTW * 32 + l) * 64;
+      const char* na = lds + (int)((h + 1) & (RING - 1)) * HB + (wr * OTW * 32 + l) * 64;
+      const char* nb = lds + (int)((h + 1) & (RING - 1)) * HB + (256 + wc * KTW * 32 + l) * 64;
+      ah[0] = nah; al[0] = nal; bh[0] = nbh; bl[0] = nbl;
+      // the schedule: every MFMA triple carries the conversion of a fragment needed later, raw rows are read one step
+      // before they are converted; the ring hand-over (wait, barrier, re-issue) sits in the middle of the half
+      Raw r = fetch_row(pa + 1 * 32 * 64);
+      DMN_FENCE();
+      triple(0, 0, ah[0], al[0], bh[0], bl[0]);
+      split(r, ah[1], al[1]); bsum[1] += row_sum(r);
+      r = fetch_row(pa + 2 * 32 * 64);
+      DMN_FENCE();
+      triple(1, 0, ah[1], al[1], bh[0], bl[0]);
+      split(r, ah[2], al[2]); bsum[2] += row_sum(r);
+      r = fetch_row(pa + 3 * 32 * 64);
+      DMN_FENCE();
+      triple(2, 0, ah[2], al[2], bh[0], bl[0]);
+      split(r, ah[3], al[3]); bsum[3] += row_sum(r);
+      r = fetch_row(pb + 1 * 32 * 64);
+      DMN_FENCE();
+      triple(3, 0, ah[3], al[3], bh[0], bl[0]);
+      split(r, bh[1], bl[1]);
+      r = fetch_row(pb + 2 * 32 * 64);
+      DMN_FENCE();
+      triple(0, 1, ah[0], al[0], bh[1], bl[1]);
+      split(r, bh[0], bl[0]);                               // B2 (B0 is done)
+      r = fetch_row(pb + 3 * 32 * 64);
+      DMN_FENCE();
+      triple(1, 1, ah[1], al[1], bh[1], bl[1]);
+      DMN_FENCE();
+      triple(2, 1, ah[2], al[2], bh[1], bl[1]);
+      DMN_FENCE();
+      triple(3, 1, ah[3], al[3], bh[1], bl[1]);
+      DMN_FENCE();
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // this wave's pieces of half h+1 (half h+2 stays in flight)
+      __syncthreads();                                     // ... everybody's; and everybody is past half h-1
+      issue(h + 3);                                        // into the slot of half h-1
+      DMN_FENCE();
+      triple(0, 2, ah[0], al[0], bh[0], bl[0]);
+      split(r, bh[1], bl[1]);                               // B3 (B1 is done)
+      Raw rn = fetch_row(na);
+      DMN_FENCE();
+      triple(1, 2, ah[1], al[1], bh[0], bl[0]);
+      split(rn, nah, nal); bsum[0] += h + 1 < H ? row_sum(rn) : 0.f;
+      rn = fetch_row(nb);
+      DMN_FENCE();
+      triple(2, 2, ah[2], al[2], bh[0], bl[0]);
+      split(rn, nbh, nbl);
+      DMN_FENCE();
+      triple(3, 2, ah[3], al[3], bh[0], bl[0]);
+      DMN_FENCE();
+      triple(0, 3, ah[0], al[0], bh[1], bl[1]);
+      DMN_FENCE();
+      triple(1, 3, ah[1], al[1], bh[1], bl[1]);
+      DMN_FENCE();
+      triple(2, 3, ah[2], al[2], bh[1], bl[1]);
+      DMN_FENCE();
+      triple(3, 3, ah[3], al[3], bh[1], bl[1]);
+      DMN_FENCE();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the ring's last (unused) fetches must land before the LDS goes
+  }
+#undef DMN_FENCE
+
+  constexpr int K = 256;
+#pragma unroll
+  for (int i = 0; i < OTW; ++i)
+#pragma unroll
+    for (int j = 0; j < KTW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = (wr * OTW + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int k = (wc * KTW + j) * 32 + l;
+        part[gm.index_off + o * K + k] = acc[i * KTW + j][r];
+      }
+  if (gm.bias_off >= 0 && wc == 0) {                       // both waves of a row block hold the same row sums
+#pragma unroll
+    for (int i = 0; i < OTW; ++i) {
+      const float v = bsum[i] + __shfl_xor(bsum[i], 32);   // the two 8-point groups of a half
+      if (kh == 0) part[gm.bias_off + (wr * OTW + i) * 32 + l] = v;
+    }
+  }
+}
+
 __global__ void field_wgrad_reduce_kernel(const float* partial, const int32_t* index, long index_len, int splits,
                                           float* grads, int accumulate) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -452,7 +633,9 @@ void launch_class(WgArgs a, const int* ids, int n, bool x3, hipStream_t st) {
     a.elem_base = kWgradBigLen;
     a.splits *= kWgradSmallSplitFactor;
   }
-  if (x3)
+  if (x3 && OT == 8 && KT == 8)
+    hipLaunchKernelGGL(field_wgrad_ring_kernel, dim3(a.splits, n), dim3(256), 0, st, a);
+  else if (x3)
     hipLaunchKernelGGL((field_wgrad_x3_kernel<OT, KT, WR, WC>), dim3(a.splits, n), dim3(256), 0, st, a);
   else
     hipLaunchKernelGGL((field_wgrad_kernel<OT, KT, WR, WC>), dim3(a.splits, n), dim3(256), 0, st, a);

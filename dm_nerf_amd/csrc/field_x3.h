@@ -157,21 +157,10 @@ __device__ __forceinline__ float acc_read(const f32x16& acc, int r) {
 
 // One layer: NT output tiles x (NKS + NKX) k-steps of 16; xh/xl: main operand fragments,
 // eh/el: extra fragments (position / direction encodings) appended to the k range.
-//
-// Chaining (x3_network): a layer's LAST tile has no successor inside the layer to hide its epilogue behind (8 pieces =
-// ~80 VALU instructions with the matrix pipe idle, 3 % of a layer).  With DEFER the layer returns with that tile still in
-// acc[1] (NT is even), and the NEXT layer runs its pieces (`prev`, tile PT of the layer before) in the shadow of its own
-// tile 0, k-steps 1..: the fragments they produce are k-steps 2 PT, 2 PT + 1 of the next layer's input, which its tile 0
-// reaches only after the pieces are done (checked below).  acc[] is the caller's, shared by the chained layers.
-struct NoEpi {
-  static constexpr bool kFragments = false;
-  __device__ __forceinline__ void operator()(int, int, float, float) const {}
-};
-
-template <class P, int NT, int NKS, int NKX, class Epi, class Prev = NoEpi, int PT = -1, bool DEFER = false>
-__device__ __forceinline__ void layer_x3(Ctx& c, f32x16 (&acc)[2], const float* bias, const typename P::frag* xh,
+template <class P, int NT, int NKS, int NKX, class Epi>
+__device__ __forceinline__ void layer_x3(Ctx& c, const float* bias, const typename P::frag* xh,
                                          const typename P::frag* xl, const typename P::frag* eh,
-                                         const typename P::frag* el, const Epi& epi, const Prev& prev = Prev()) {
+                                         const typename P::frag* el, const Epi& epi) {
   typedef typename P::frag frag;
   constexpr int NK = NKS + NKX;
   constexpr int STEPS = NT * NK;
@@ -180,10 +169,7 @@ __device__ __forceinline__ void layer_x3(Ctx& c, f32x16 (&acc)[2], const float* 
   // accumulator, >= 96 cycles) covers the result latency of the finished tile's last MFMA.  acc_read() is inline
   // asm, for which the compiler inserts no MFMA -> VALU hazard nops; reading earlier returns a stale accumulator.
   constexpr int PPS = (8 + NK - 2) / (NK - 1);
-  static_assert(!DEFER || (NT & 1) == 0, "a deferred last tile must sit in acc[1]");
-  static_assert(PT < 0 || ((PT & 1) == 1 && (!Prev::kFragments || (8 + PPS - 1) / PPS < 2 * PT)),
-                "the previous layer's last tile is in acc[1] and, where its epilogue makes operand fragments (k-steps 2 PT, "
-                "2 PT + 1 of this layer's input), they must be complete before this layer's tile 0 reads them");
+  f32x16 acc[2];
   constexpr int PF = DMN_X3_PREFETCH;       // A-fragment prefetch distance in steps; ring of PF + 1
   frag ah[PF + 1], al[PF + 1];
 #pragma unroll
@@ -215,11 +201,6 @@ __device__ __forceinline__ void layer_x3(Ctx& c, f32x16 (&acc)[2], const float* 
         for (int q = (ks - 1) * PPS; q < ks * PPS && q < 8; ++q)
           epi(t - 1, q, acc_read(acc[(t - 1) & 1], 2 * q), acc_read(acc[(t - 1) & 1], 2 * q + 1));
       }
-      if (PT >= 0 && t == 0 && ks > 0) {   // the layer before left its last tile in acc[1]
-#pragma unroll
-        for (int q = (ks - 1) * PPS; q < ks * PPS && q < 8; ++q)
-          prev(PT < 0 ? 0 : PT, q, acc_read(acc[1], 2 * q), acc_read(acc[1], 2 * q + 1));
-      }
       const frag bh = ks < NKS ? xh[ks < NKS ? ks : 0] : eh[ks < NKS ? 0 : ks - NKS];
       const frag bl = ks < NKS ? xl[ks < NKS ? ks : 0] : el[ks < NKS ? 0 : ks - NKS];
       acc[t & 1] = P::mfma(ah[step % (PF + 1)], bl, acc[t & 1]);
@@ -232,28 +213,10 @@ __device__ __forceinline__ void layer_x3(Ctx& c, f32x16 (&acc)[2], const float* 
 #pragma unroll
     for (int q = (STEPS & 31); q < 16; ++q) load_piece(c, q);
   }
-  if (!DEFER) {
-    // the last tile has no successor to hide behind: plain register reads, so that the compiler sees the MFMA -> VALU
-    // dependency and inserts the wait states itself
+  // the last tile has no successor to hide behind: plain register reads, so that the compiler sees the MFMA -> VALU
+  // dependency and inserts the wait states itself
 #pragma unroll
-    for (int q = 0; q < 8; ++q) epi(NT - 1, q, acc[(NT - 1) & 1][2 * q], acc[(NT - 1) & 1][2 * q + 1]);
-  }
-}
-
-// a deferred last tile that no layer follows (early exits): its epilogue in the open
-template <class Epi>
-__device__ __forceinline__ void flush_deferred(f32x16 (&acc)[2], const Epi& epi, int tile) {
-#pragma unroll
-  for (int q = 0; q < 8; ++q) epi(tile, q, acc[1][2 * q], acc[1][2 * q + 1]);
-}
-
-// stand-alone layer (no chaining): its own accumulators
-template <class P, int NT, int NKS, int NKX, class Epi>
-__device__ __forceinline__ void layer_x3(Ctx& c, const float* bias, const typename P::frag* xh,
-                                         const typename P::frag* xl, const typename P::frag* eh,
-                                         const typename P::frag* el, const Epi& epi) {
-  f32x16 acc[2];
-  layer_x3<P, NT, NKS, NKX, Epi>(c, acc, bias, xh, xl, eh, el, epi);
+  for (int q = 0; q < 8; ++q) epi(NT - 1, q, acc[(NT - 1) & 1][2 * q], acc[(NT - 1) & 1][2 * q + 1]);
 }
 
 

@@ -5,10 +5,6 @@
 #pragma once
 #include "field_x3.h"
 
-#ifndef DMN_X3_DEFER
-#define DMN_X3_DEFER 1
-#endif
-
 namespace dmn {
 
 // Inference epilogues: DENS is compile-time -- as a run-time flag every epilogue piece carried a branch that cut the MFMA
@@ -20,7 +16,6 @@ struct EpiSplit {
   float* amax;
   float* sigma;          // density accumulation (DENS)
   const float* dw;       // density weights of this lane-half
-  static constexpr bool kFragments = true;      // its pieces make operand fragments of the next layer
   __device__ __forceinline__ void operator()(int t, int q, float x0, float x1) const {
     if (RELU) {
       x0 = relu_bits(x0);
@@ -40,7 +35,6 @@ struct EpiSplit {
 struct EpiRgb {
   float* rgb;            // [3] partial sums of this lane-half
   const float* rw;       // cst + kConstRgbW + h*64
-  static constexpr bool kFragments = false;
   __device__ __forceinline__ void operator()(int t, int q, float a0, float a1) const {
     const float x0 = relu_bits(a0), x1 = relu_bits(a1);
 #pragma unroll
@@ -71,71 +65,65 @@ __device__ __forceinline__ void x3_network(Ctx& c, const float* cst, const typen
                                            float& sigma, float (&rgb)[3], float (&insv)[16 * T]) {
   typedef typename P::frag frag;
   frag act_h[16], act_l[16], nxt_h[16], nxt_l[16];
-  f32x16 acc[2];               // shared by the chained layers (field_x3.h: a layer's last tile is finished by the next)
   sigma = 0.f;
   const float* const dw = cst + kConstDensW + h * 128;
   typedef EpiSplit<P, true, false> Relu;
   typedef EpiSplit<P, true, true> ReluDens;
   typedef EpiSplit<P, false, false> Lin;
-  const Relu to_act{act_h, act_l, &amax, &sigma, dw}, to_nxt{nxt_h, nxt_l, &amax, &sigma, dw};
-  constexpr bool D = DMN_X3_DEFER != 0;      // chain the layers (field_x3.h); 0 = every layer finishes its own last tile
-  constexpr int P7 = D ? 7 : -1, P3 = D ? 3 : -1;
 
   // ---- mlps.0: position encoding (4 k-steps) -> act
-  layer_x3<P, 8, 4, 0, Relu, NoEpi, -1, D>(c, acc, cst + kConstBias8 + h * 128, pe_h, pe_l, pe_h, pe_l, to_act);
-  // ---- mlps.1 .. mlps.4 in ping-pong pairs (rolled: a layer pair is ~3000 instructions)
+  layer_x3<P, 8, 4, 0>(c, cst + kConstBias8 + h * 128, pe_h, pe_l, pe_h, pe_l, Relu{act_h, act_l, &amax, &sigma, dw});
+  // ---- mlps.1 .. mlps.5 in ping-pong pairs (rolled: a layer pair is ~3000 instructions); mlps.5 (skip connection)
+  //      also consumes the position encoding
   int l = 1;
 #pragma unroll 1
   for (int it = 0; it < 2; ++it) {
-    layer_x3<P, 8, 16, 0, Relu, Relu, P7, D>(c, acc, cst + kConstBias8 + l * 256 + h * 128, act_h, act_l, pe_h, pe_l,
-                                               to_nxt, to_act);
+    layer_x3<P, 8, 16, 0>(c, cst + kConstBias8 + l * 256 + h * 128, act_h, act_l, pe_h, pe_l,
+                          Relu{nxt_h, nxt_l, &amax, &sigma, dw});
     ++l;
-    layer_x3<P, 8, 16, 0, Relu, Relu, P7, D>(c, acc, cst + kConstBias8 + l * 256 + h * 128, nxt_h, nxt_l, pe_h, pe_l,
-                                               to_act, to_nxt);
+    layer_x3<P, 8, 16, 0>(c, cst + kConstBias8 + l * 256 + h * 128, nxt_h, nxt_l, pe_h, pe_l,
+                          Relu{act_h, act_l, &amax, &sigma, dw});
     ++l;
+    if (it == 1) {
+      layer_x3<P, 8, 16, 4>(c, cst + kConstBias8 + l * 256 + h * 128, act_h, act_l, pe_h, pe_l,
+                            Relu{nxt_h, nxt_l, &amax, &sigma, dw});
+      ++l;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        act_h[k] = nxt_h[k];
+        act_l[k] = nxt_l[k];
+      }
+    }
   }
-  // ---- mlps.5 (skip connection: also consumes the position encoding) -> nxt, mlps.6 -> act, and mlps.7 -> nxt with the
-  //      density head's partial sums (its own instantiation: DENS is compile-time)
-  layer_x3<P, 8, 16, 4, Relu, Relu, P7, D>(c, acc, cst + kConstBias8 + 5 * 256 + h * 128, act_h, act_l, pe_h, pe_l,
-                                             to_nxt, to_act);
-  layer_x3<P, 8, 16, 0, Relu, Relu, P7, D>(c, acc, cst + kConstBias8 + 6 * 256 + h * 128, nxt_h, nxt_l, pe_h, pe_l,
-                                             to_act, to_nxt);
-  const ReluDens trunk{nxt_h, nxt_l, &amax, &sigma, dw};
-  layer_x3<P, 8, 16, 0, ReluDens, Relu, P7, D>(c, acc, cst + kConstBias8 + 7 * 256 + h * 128, act_h, act_l, pe_h, pe_l,
-                                                 trunk, to_act);
+  // ---- mlps.6, and mlps.7 with the density head's partial sums (its own instantiation: DENS is compile-time)
+  layer_x3<P, 8, 16, 0>(c, cst + kConstBias8 + 6 * 256 + h * 128, act_h, act_l, pe_h, pe_l,
+                        Relu{nxt_h, nxt_l, &amax, &sigma, dw});
+  layer_x3<P, 8, 16, 0>(c, cst + kConstBias8 + 7 * 256 + h * 128, nxt_h, nxt_l, pe_h, pe_l,
+                        ReluDens{act_h, act_l, &amax, &sigma, dw});
+  // ---- density_linear (dm_nerf.py:101): fp32 partial sums were taken while mlps.7 was converted
+  sigma += __shfl_xor(sigma, 32);
+  sigma += cst[kConstDensB];
   rgb[0] = 0.f; rgb[1] = 0.f; rgb[2] = 0.f;
 #pragma unroll
   for (int i = 0; i < 16 * T; ++i) insv[i] = 0.f;
-  if (sigma_only) {            // density is all the caller wants (the coarse pass of an image loop feeds the resampler)
-    if (D) flush_deferred(acc, trunk, 7);
-    sigma += __shfl_xor(sigma, 32);
-    sigma += cst[kConstDensB];
-    return;
-  }
+  if (sigma_only) return;      // density is all the caller wants (the coarse pass of an image loop feeds the resampler)
 
-  // ---- rgb_feature_linear on the trunk output nxt (no activation) -> act; it finishes mlps.7's last tile, after which the
-  //      density_linear partial sums (dm_nerf.py:101) are complete
-  const Lin lin_act{act_h, act_l, &amax, &sigma, dw};
-  layer_x3<P, 8, 16, 0, Lin, ReluDens, P7, D>(c, acc, cst + kConstBias8 + 8 * 256 + h * 128, nxt_h, nxt_l, pe_h, pe_l,
-                                                lin_act, trunk);
-  sigma += __shfl_xor(sigma, 32);
-  sigma += cst[kConstDensB];
-  // ---- rgb_feature_linears.0 on [feature, dirs] -> rgb_linear on the VALU
-  const EpiRgb to_rgb{rgb, cst + kConstRgbW + h * 64};
-  layer_x3<P, 4, 16, 2, EpiRgb, Lin, P7, D>(c, acc, cst + kConstBias4 + h * 64, act_h, act_l, qe_h, qe_l, to_rgb, lin_act);
-  // ---- ins_feature_linear on the trunk output (no activation) -> act; ins_feature_linears.0 (ReLU) -> nxt[0..7]
-  layer_x3<P, 8, 16, 0, Lin, EpiRgb, P3, D>(c, acc, cst + kConstBias8 + 9 * 256 + h * 128, nxt_h, nxt_l, pe_h, pe_l,
-                                              lin_act, to_rgb);
+  // ---- rgb_feature_linear (no activation) -> nxt; rgb_feature_linears.0 on [feature, dirs] -> rgb_linear
+  layer_x3<P, 8, 16, 0>(c, cst + kConstBias8 + 8 * 256 + h * 128, act_h, act_l, pe_h, pe_l,
+                        Lin{nxt_h, nxt_l, &amax, &sigma, dw});
+  layer_x3<P, 4, 16, 2>(c, cst + kConstBias4 + h * 64, nxt_h, nxt_l, qe_h, qe_l, EpiRgb{rgb, cst + kConstRgbW + h * 64});
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     rgb[k] += __shfl_xor(rgb[k], 32);
     rgb[k] += cst[kConstRgbB + k];
   }
-  layer_x3<P, 4, 16, 0, Relu, Lin, P7, D>(c, acc, cst + kConstBias4 + 128 + h * 64, act_h, act_l, pe_h, pe_l, to_nxt,
-                                            lin_act);
+  // ---- ins_feature_linear on the trunk output (no activation) -> nxt; ins_feature_linears.0 (ReLU) -> act[0..7]
+  layer_x3<P, 8, 16, 0>(c, cst + kConstBias8 + 9 * 256 + h * 128, act_h, act_l, pe_h, pe_l,
+                        Lin{nxt_h, nxt_l, &amax, &sigma, dw});
+  layer_x3<P, 4, 16, 0>(c, cst + kConstBias4 + 128 + h * 64, nxt_h, nxt_l, pe_h, pe_l,
+                        Relu{act_h, act_l, &amax, &sigma, dw});
   // ---- ins_linear: 128 -> ins_num + 1, T tiles, kept in registers
-  layer_x3<P, T, 8, 0, EpiKeep, Relu, P3, false>(c, acc, cst + kConstBiasO + h * 64, nxt_h, nxt_l, pe_h, pe_l,
-                                                EpiKeep{insv}, to_nxt);
+  layer_x3<P, T, 8, 0>(c, cst + kConstBiasO + h * 64, act_h, act_l, pe_h, pe_l, EpiKeep{insv});
 }
 
 // pts = o + d z, viewdirs, encodings and their hi / lo operand fragments for point mc (render.py:37-38,49-58)

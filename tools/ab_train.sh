@@ -11,7 +11,7 @@ sys.path.insert(0, os.getcwd())
 import dm_nerf_amd as dm
 from dm_nerf_amd import ops, synthetic, trainer
 dev = torch.device("cuda", 0)
-args = dm.default_args(ins_num=13, perturb=1.0, is_train=True, precision="bf16x3", device=dev)
+args = dm.default_args(ins_num=13, perturb=1.0, is_train=True, precision=os.environ.get("AB_PREC", "bf16x3"), device=dev)
 pos, view, coarse, fine, args = dm.create_nerf(args)
 coarse.load_state_dict(synthetic.make_params(13, 0)); fine.load_state_dict(synthetic.make_params(13, 1))
 K, c2w = synthetic.dmsr_intrinsics(800, 800), synthetic.study_pose(1)

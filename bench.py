@@ -103,16 +103,17 @@ def training_leg(nerf, K, pose, device, n_rays: int = 4096, steps: int = 4):
     for prec in ("fp32", "bf16x3"):
         targs.precision = prec
         opt = trainer.make_optimizer(coarse, fine)
-        run = lambda i: trainer.train_step(
+        # losses are read back on the last timed step only (the reference reads them every i_print steps, train_dmsr.py:75)
+        run = lambda i, report=False: trainer.train_step(
             i, rays, target, (pos, view, coarse, fine, targs), z, opt,
             ins_loss=lambda pred: dm.ins_criterion(pred, labels, INS_NUM)[0],
-            penalizer=lambda raw, zz, depth: dm.ins_penalizer(raw, zz, depth, rays[1], targs))
+            penalizer=lambda raw, zz, depth: dm.ins_penalizer(raw, zz, depth, rays[1], targs), report=report)
         run(0)
         torch.cuda.synchronize()
         ops.PROFILE = []
         t0 = time.perf_counter()
         for i in range(steps):
-            last = run(i + 1)
+            last = run(i + 1, report=i == steps - 1)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         prof, ops.PROFILE = ops.PROFILE, None

@@ -33,14 +33,18 @@ def decayed_lrate(i: int, lrate: float, lrate_decay: int) -> float:
 
 def train_step(i: int, batch_rays, target_rgb, nerf, z_vals_coarse, optimizer, lrate: float = 5e-4,
                lrate_decay: int = 500, ins_loss: Optional[Callable] = None, penalizer: Optional[Callable] = None,
-               allreduce: Optional[Callable] = None, shard: Optional[Tuple[int, int]] = None) -> Dict[str, float]:
+               allreduce: Optional[Callable] = None, shard: Optional[Tuple[int, int]] = None,
+               report: bool = True) -> Dict[str, float]:
     """One optimisation step (train_dmsr.py:32-72).  ``nerf`` is the tuple ``create_nerf`` returns.
     ``allreduce(models)`` is called between backward and the optimizer step (data-parallel training).
 
     Ray-sharded, batch-exact step: pass ``shard=(rays of this rank, rays of the whole batch)``,
     loss heads built with ``reduce=parallel.ShardReducer(group)`` and ``allreduce=lambda m: bucket.allreduce(group)``
     (a SUM): the colour terms are weighted by the shard's share of the batch, the instance / emptiness terms see the
-    whole batch's statistics, so the summed gradient is that of the unsharded loss for shards of any sizes."""
+    whole batch's statistics, so the summed gradient is that of the unsharded loss for shards of any sizes.
+
+    Returns the loss terms as floats (one device read-back), or with ``report=False`` as detached 0-dim tensors without
+    waiting for the device."""
     position_embedder, view_embedder, model_coarse, model_fine, args = nerf
     out = dm_nerf(batch_rays, position_embedder, view_embedder, model_coarse, model_fine, z_vals_coarse, args)
     mse_c = torch.mean((out["rgb_coarse"] - target_rgb) ** 2)                       # img2mse, evaluator.py:11
@@ -62,6 +66,8 @@ def train_step(i: int, batch_rays, target_rgb, nerf, z_vals_coarse, optimizer, l
     optimizer.step()
     for group in optimizer.param_groups:                                            # applied after the step, :68-72
         group["lr"] = decayed_lrate(i, lrate, lrate_decay)
+    if not report:      # no read-back: the device keeps running into the next step (the reference reads its losses only
+        return {**{k: v.detach() for k, v in terms.items()}, "total": total.detach()}      # every i_print steps, :74-80)
     names = list(terms) + ["total"]                                 # one read-back for all of them
     vals = torch.stack([v.detach().float().reshape(()) for v in terms.values()] + [total.detach().float()]).tolist()
     report = dict(zip(names, vals))

@@ -72,7 +72,7 @@ reduce_grads = (lambda models: bucket.allreduce()) if world > 1 else None       
 
 def step(i):
     return trainer.train_step(i, rays, target, (pos, view, coarse, fine, args), z, opt, ins_loss=ins, penalizer=pen,
-                              allreduce=reduce_grads, shard=(hi - lo, ns.rays) if world > 1 else None)
+                              allreduce=reduce_grads, shard=(hi - lo, ns.rays) if world > 1 else None, report=False)
 
 
 def barrier():

@@ -619,9 +619,17 @@ __global__ void field_wgrad_reduce_kernel(const float* partial, const int32_t* i
   const long len = big ? kWgradBigLen : index_len - kWgradBigLen;
   const float* p = big ? partial + e : partial + (long)splits * kWgradBigLen + (e - kWgradBigLen);
   const int n = big ? splits : splits * kWgradSmallSplitFactor;
-  float v = 0.f;
-  for (int s = 0; s < n; ++s) v += p[(long)s * len];
-  grads[dst] = accumulate ? grads[dst] + v : v;
+  // eight loads in flight per thread (the slices are 2.4 MB apart: a dependent chain of single loads ran at 1.2 TB/s);
+  // fixed association, so the sum is deterministic
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+  for (; s + 8 <= n; s += 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += __builtin_nontemporal_load(p + (long)(s + j) * len);
+  }
+  for (int j = 0; s < n; ++s, ++j) v[j] += __builtin_nontemporal_load(p + (long)s * len);
+  const float sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  grads[dst] = accumulate ? grads[dst] + sum : sum;
 }
 
 template <int OT, int KT, int WR, int WC>

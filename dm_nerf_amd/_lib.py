@@ -70,6 +70,7 @@ SIGNATURES = {
     "dmn_field_wgrad_workspace_floats": (c_long, [c_int, c_int]),
     "dmn_field_bwd_weights": (c_int, [_P, _P, c_long, c_int, _P, c_int, c_int, _P, _P, c_int, _P]),
     "dmn_penalizer_fwd": (c_int, [_P, _P, c_long, _P, _P, c_long, c_int, c_int, c_float, c_float, _P, _P]),
+    "dmn_penalizer_loss": (c_int, [_P, c_int, _P, _P]),
     "dmn_penalizer_bwd": (c_int, [_P, _P, c_long, _P, _P, c_long, c_int, c_int, c_float, c_float, _P, _P, _P, _P]),
     "dmn_ins_stats_fwd": (c_int, [_P, _P, _P, c_long, c_int, c_int, _P, _P]),
     "dmn_ins_stats_bwd": (c_int, [_P, _P, c_long, c_int, c_int, _P, _P, _P]),

@@ -112,6 +112,12 @@ __global__ __launch_bounds__(256) void penalizer_bwd_kernel(const PenArgs a, con
   g_raw[e] = v;
 }
 
+// loss = sum L_before / ((ins_num + 1) max(sum before, 1e-8)) + sum L_middle / max(sum middle, 1e-8) in fp64, as the
+// host-side tensor formula computes it (one launch instead of eight small ones)
+__global__ void penalizer_loss_kernel(const double* sums, int K, float* loss) {
+  loss[0] = (float)(sums[0] / ((double)K * fmax(sums[1], 1e-8)) + sums[2] / fmax(sums[3], 1e-8));
+}
+
 PenArgs make_args(const float* raw, const float* z, long z_stride, const float* depth, const float* rays_d, long n,
                   int S, int C, float tolerance, float deta_w, double* sums) {
   const float w2 = deta_w * deta_w;                       // torch: delta_W ** 2 on an fp32 tensor
@@ -133,6 +139,12 @@ extern "C" int dmn_penalizer_fwd(const float* raw, const float* z, long z_ray_st
   const long total = n_rays * n_samples;
   const PenArgs a = make_args(raw, z, z_ray_stride, depth, rays_d, n_rays, n_samples, channels, tolerance, deta_w, sums4);
   hipLaunchKernelGGL(penalizer_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+  return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
+}
+
+extern "C" int dmn_penalizer_loss(const double* sums4, int channels, float* loss, void* stream) {
+  if (!sums4 || !loss || channels < 5) return DMN_ERR_BAD_ARG;
+  hipLaunchKernelGGL(penalizer_loss_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sums4, channels - 4, loss);
   return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
 }
 

@@ -24,9 +24,9 @@ class _PenalizerFn(torch.autograd.Function):
             sums = reduce("penalizer_sums", sums)          # (penalizer.py:42-43,52 normalise by the batch's mask sums)
         ctx.save_for_backward(raw, zz, depth, rays_d, sums)
         ctx.meta = (stride, float(tolerance), float(deta_w))
-        tiny = torch.full((), 1e-8, dtype=torch.float64, device=raw.device)
-        loss = sums[0] / ((c - 4) * torch.maximum(sums[1], tiny)) + sums[2] / torch.maximum(sums[3], tiny)
-        return loss.float()
+        loss = torch.empty(1, dtype=torch.float32, device=raw.device)
+        check(load().dmn_penalizer_loss(ptr(sums), c, ptr(loss), current_stream()), "dmn_penalizer_loss")
+        return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g_loss):

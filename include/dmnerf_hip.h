@@ -204,6 +204,8 @@ int dmn_field_bwd_weights(const float* save, const float* grad_record, long n_po
 int dmn_penalizer_fwd(const float* raw, const float* z, long z_ray_stride, const float* depth, const float* rays_d,
                       long n_rays, int n_samples, int channels, float tolerance, float deta_w, double* sums4,
                       void* stream);
+/* loss [1] from the four sums (fp64 arithmetic, rounded to fp32 at the end): penalizer.py:42-43,52 */
+int dmn_penalizer_loss(const double* sums4, int channels, float* loss, void* stream);
 int dmn_penalizer_bwd(const float* raw, const float* z, long z_ray_stride, const float* depth, const float* rays_d,
                       long n_rays, int n_samples, int channels, float tolerance, float deta_w, const double* sums4,
                       const float* g_loss, float* g_raw, void* stream);

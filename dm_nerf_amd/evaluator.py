@@ -64,7 +64,7 @@ def _label_prep(labels: torch.Tensor, ins_num: int):
 
 class _InsCriterionFn(torch.autograd.Function):
     """The whole loss head on the device in five launches, one read-back (cost matrix) and one upload (the matching):
-    pred [N, K], labels [N] -> [sum, valid_ce, invalid_ce, valid_siou].  Returns None for inputs the fused kernels do
+    pred [N, K], labels [N] -> (sum, valid_ce, invalid_ce, valid_siou).  Returns Nones for inputs the fused kernels do
     not take (labels outside [0, 1024), more labels than columns): the caller falls back to the tensor-op path."""
 
     @staticmethod
@@ -85,7 +85,7 @@ class _InsCriterionFn(torch.autograd.Function):
         host = blob.cpu().numpy()                                                     # the step's one wait for the device
         v = int(host[0])
         if host[1] != 0.0 or v == 0:
-            return None
+            return None, None, None, None
         rows, cols = linear_sum_assignment(host[2:].reshape(ins_num, k)[:v])           # reorder(), :42-52
         match = np.full(ins_num + k, -1, dtype=np.int32)
         match[rows] = cols                                                            # col_of [ins_num]
@@ -96,17 +96,18 @@ class _InsCriterionFn(torch.autograd.Function):
                                ins_num, ptr(out), st), "dmn_ins_loss")
         ctx.save_for_backward(pred, classes, stats, count, colsum, match_t, meta)
         ctx.ins_num = ins_num
-        return out
+        ctx.set_materialize_grads(False)               # terms nobody differentiates arrive as None, not as zero tensors
+        return out[0], out[1], out[2], out[3]          # four outputs of this node (no select nodes, no zero-fills behind them)
 
     @staticmethod
-    def backward(ctx, g_out):
+    def backward(ctx, g_total, g_ce, g_inv, g_siou):
         pred, classes, stats, count, colsum, match_t, meta = ctx.saved_tensors
         lib, st = load(), current_stream()
         n, k = pred.shape
-        g = g_out.float().contiguous()                 # [4]: gradients of sum, valid_ce, invalid_ce, valid_siou
+        g = [None if t is None else t.reshape(1).float().contiguous() for t in (g_total, g_ce, g_inv, g_siou)]
         g_stats = torch.empty_like(stats)
         check(lib.dmn_ins_loss_bwd(ptr(stats), ptr(count), ptr(colsum), ptr(match_t) + 4 * ctx.ins_num, ptr(meta), n, k,
-                                   ctx.ins_num, ptr(g), ptr(g) + 4, ptr(g) + 8, ptr(g) + 12, ptr(g_stats), st),
+                                   ctx.ins_num, ptr(g[0]), ptr(g[1]), ptr(g[2]), ptr(g[3]), ptr(g_stats), st),
               "dmn_ins_loss_bwd")
         g_pred = torch.empty_like(pred)
         check(lib.dmn_ins_stats_bwd(ptr(pred), ptr(classes), n, k, ctx.ins_num, ptr(g_stats), ptr(g_pred), st),
@@ -136,8 +137,8 @@ def ins_criterion(pred_ins: torch.Tensor, gt_labels: torch.Tensor, ins_num: int,
         # five launches instead of ~100 tensor operations (the host is the bottleneck of this part of a training step);
         # ``fused=False`` is the same arithmetic written with tensor operations (and the only form under ``reduce``)
         got = _InsCriterionFn.apply(pred_ins, labels.to(pred_ins.device).contiguous(), ins_num)
-        if got is not None:
-            return got[0], got[1], got[2], got[3]
+        if got[0] is not None:
+            return got
     if reduce is None:
         valid, classes = torch.unique(labels, return_inverse=True)                    # :21, :25 (sorted labels)
         v = int(valid.numel())                                                        # :24

@@ -106,7 +106,7 @@ def training_leg(nerf, K, pose, device, n_rays: int = 4096, steps: int = 4):
         # losses are read back on the last timed step only (the reference reads them every i_print steps, train_dmsr.py:75)
         run = lambda i, report=False: trainer.train_step(
             i, rays, target, (pos, view, coarse, fine, targs), z, opt,
-            ins_loss=lambda pred: dm.ins_criterion(pred, labels, INS_NUM)[0],
+            ins_loss=trainer.instance_loss(labels, INS_NUM),
             penalizer=lambda raw, zz, depth: dm.ins_penalizer(raw, zz, depth, rays[1], targs), report=report)
         run(0)
         torch.cuda.synchronize()

@@ -11,7 +11,7 @@ ROCm device the calls raise."""
 from ._lib import HipLibraryError, LIB_PATH, load as load_library
 from .config import create_nerf, default_args
 from .dm_nerf import DM_NeRF, Embedder, get_embedder
-from .evaluator import img2mse, ins_criterion, mse2psnr
+from .evaluator import img2mse, ins_criterion, ins_criterion_many, mse2psnr
 from .helpers import get_rays_k, get_select_crop, get_select_full, sample_pdf, z_val_sample
 from .manipulator import exchanger, manipulator, manipulator_nerf, manipulator_render
 from .penalizer import emptiness_penalizer, ins_penalizer
@@ -26,7 +26,7 @@ render_path = render_test
 
 __all__ = [
     "HipLibraryError", "LIB_PATH", "load_library", "create_nerf", "default_args", "DM_NeRF", "Embedder",
-    "get_embedder", "emptiness_penalizer", "ins_penalizer", "ins_criterion", "img2mse", "mse2psnr", "get_rays_k", "get_select_full", "get_select_crop", "sample_pdf", "z_val_sample", "manipulator_nerf", "manipulator_render", "exchanger", "manipulator",
+    "get_embedder", "emptiness_penalizer", "ins_penalizer", "ins_criterion", "ins_criterion_many", "img2mse", "mse2psnr", "get_rays_k", "get_select_full", "get_select_crop", "sample_pdf", "z_val_sample", "manipulator_nerf", "manipulator_render", "exchanger", "manipulator",
     "dm_nerf", "render_train", "render_image", "render_test", "render", "raw2outputs", "render_path", "parallel",
     "trainer",
 ]

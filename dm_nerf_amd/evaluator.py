@@ -63,56 +63,84 @@ def _label_prep(labels: torch.Tensor, ins_num: int):
 
 
 class _InsCriterionFn(torch.autograd.Function):
-    """The whole loss head on the device in five launches, one read-back (cost matrix) and one upload (the matching):
-    pred [N, K], labels [N] -> (sum, valid_ce, invalid_ce, valid_siou).  Returns Nones for inputs the fused kernels do
-    not take (labels outside [0, 1024), more labels than columns): the caller falls back to the tensor-op path."""
+    """The whole loss head on the device, for one or several predictions that share their labels (the coarse and the fine
+    map of a training step): per prediction five launches, and for all of them together ONE read-back (the cost matrices)
+    and one upload (the matchings).  ``apply(labels, ins_num, *preds)`` -> (sum, valid_ce, invalid_ce, valid_siou) per
+    prediction, flattened; all None for inputs the fused kernels do not take (labels outside [0, 1024), more labels than
+    columns): the caller falls back to the tensor-operation path."""
 
     @staticmethod
-    def forward(ctx, pred, labels, ins_num):
+    def forward(ctx, labels, ins_num, *preds):
         from scipy.optimize import linear_sum_assignment
         lib = load()
-        pred = ops._dev(pred, "pred_ins").contiguous()
-        n, k = pred.shape
-        dev, st = pred.device, current_stream()
+        preds = [ops._dev(p, "pred_ins").contiguous() for p in preds]
+        n, k = preds[0].shape
+        dev, st = preds[0].device, current_stream()
         classes, count, meta = _label_prep(labels, ins_num)
-        stats = torch.empty(3, ins_num, k, dtype=torch.float32, device=dev)
-        check(lib.dmn_ins_stats_scan(ptr(pred), ptr(classes), n, k, ins_num, ptr(stats), st), "dmn_ins_stats_scan")
-        cost = torch.empty(2, ins_num, k, dtype=torch.float32, device=dev)
-        colsum = torch.empty(2, k, dtype=torch.float32, device=dev)
-        blob = torch.empty(2 + ins_num * k, dtype=torch.float32, device=dev)
-        check(lib.dmn_ins_cost(ptr(stats), ptr(count), ptr(meta), n, k, ins_num, ptr(cost), ptr(colsum), ptr(blob), st),
-              "dmn_ins_cost")
-        host = blob.cpu().numpy()                                                     # the step's one wait for the device
-        v = int(host[0])
-        if host[1] != 0.0 or v == 0:
-            return None, None, None, None
-        rows, cols = linear_sum_assignment(host[2:].reshape(ins_num, k)[:v])           # reorder(), :42-52
-        match = np.full(ins_num + k, -1, dtype=np.int32)
-        match[rows] = cols                                                            # col_of [ins_num]
-        match[ins_num + cols] = rows                                                  # class_of [k]
+        m, stride = len(preds), 2 + ins_num * k
+        stats = torch.empty(m, 3, ins_num, k, dtype=torch.float32, device=dev)
+        cost = torch.empty(m, 2, ins_num, k, dtype=torch.float32, device=dev)
+        colsum = torch.empty(m, 2, k, dtype=torch.float32, device=dev)
+        blob = torch.empty(m, stride, dtype=torch.float32, device=dev)
+        for i, pred in enumerate(preds):
+            check(lib.dmn_ins_stats_scan(ptr(pred), ptr(classes), n, k, ins_num, ptr(stats[i]), st), "dmn_ins_stats_scan")
+            check(lib.dmn_ins_cost(ptr(stats[i]), ptr(count), ptr(meta), n, k, ins_num, ptr(cost[i]), ptr(colsum[i]),
+                                   ptr(blob[i]), st), "dmn_ins_cost")
+        host = blob.cpu().numpy()                                                     # the one wait for the device
+        v = int(host[0, 0])
+        if host[0, 1] != 0.0 or v == 0:
+            return (None,) * (4 * m)
+        match = np.full((m, ins_num + k), -1, dtype=np.int32)
+        for i in range(m):
+            rows, cols = linear_sum_assignment(host[i, 2:].reshape(ins_num, k)[:v])    # reorder(), :42-52
+            match[i, rows] = cols                                                     # col_of [ins_num]
+            match[i, ins_num + cols] = rows                                           # class_of [k]
         match_t = torch.from_numpy(match).to(dev)
-        out = torch.empty(4, dtype=torch.float32, device=dev)
-        check(lib.dmn_ins_loss(ptr(cost), ptr(colsum), ptr(match_t), ptr(match_t) + 4 * ins_num, ptr(meta), n, k,
-                               ins_num, ptr(out), st), "dmn_ins_loss")
-        ctx.save_for_backward(pred, classes, stats, count, colsum, match_t, meta)
+        out = torch.empty(m, 4, dtype=torch.float32, device=dev)
+        for i in range(m):
+            check(lib.dmn_ins_loss(ptr(cost[i]), ptr(colsum[i]), ptr(match_t[i]), ptr(match_t[i]) + 4 * ins_num, ptr(meta),
+                                   n, k, ins_num, ptr(out[i]), st), "dmn_ins_loss")
+        ctx.save_for_backward(classes, stats, count, colsum, match_t, meta, *preds)
         ctx.ins_num = ins_num
         ctx.set_materialize_grads(False)               # terms nobody differentiates arrive as None, not as zero tensors
-        return out[0], out[1], out[2], out[3]          # four outputs of this node (no select nodes, no zero-fills behind them)
+        return tuple(out[i, j] for i in range(m) for j in range(4))      # outputs of this node: no select nodes behind them
 
     @staticmethod
-    def backward(ctx, g_total, g_ce, g_inv, g_siou):
-        pred, classes, stats, count, colsum, match_t, meta = ctx.saved_tensors
+    def backward(ctx, *grads):
+        classes, stats, count, colsum, match_t, meta, *preds = ctx.saved_tensors
         lib, st = load(), current_stream()
-        n, k = pred.shape
-        g = [None if t is None else t.reshape(1).float().contiguous() for t in (g_total, g_ce, g_inv, g_siou)]
-        g_stats = torch.empty_like(stats)
-        check(lib.dmn_ins_loss_bwd(ptr(stats), ptr(count), ptr(colsum), ptr(match_t) + 4 * ctx.ins_num, ptr(meta), n, k,
-                                   ctx.ins_num, ptr(g[0]), ptr(g[1]), ptr(g[2]), ptr(g[3]), ptr(g_stats), st),
-              "dmn_ins_loss_bwd")
-        g_pred = torch.empty_like(pred)
-        check(lib.dmn_ins_stats_bwd(ptr(pred), ptr(classes), n, k, ctx.ins_num, ptr(g_stats), ptr(g_pred), st),
-              "dmn_ins_stats_bwd")
-        return g_pred, None, None
+        n, k = preds[0].shape
+        g_preds = []
+        for i, pred in enumerate(preds):
+            g4 = grads[4 * i: 4 * i + 4]
+            if all(t is None for t in g4):
+                g_preds.append(None)
+                continue
+            g = [None if t is None else t.reshape(1).float().contiguous() for t in g4]
+            g_stats = torch.empty_like(stats[i])
+            check(lib.dmn_ins_loss_bwd(ptr(stats[i]), ptr(count), ptr(colsum[i]), ptr(match_t[i]) + 4 * ctx.ins_num,
+                                       ptr(meta), n, k, ctx.ins_num, ptr(g[0]), ptr(g[1]), ptr(g[2]), ptr(g[3]),
+                                       ptr(g_stats), st), "dmn_ins_loss_bwd")
+            g_pred = torch.empty_like(pred)
+            check(lib.dmn_ins_stats_bwd(ptr(pred), ptr(classes), n, k, ctx.ins_num, ptr(g_stats), ptr(g_pred), st),
+                  "dmn_ins_stats_bwd")
+            g_preds.append(g_pred)
+        return (None, None, *g_preds)
+
+
+def ins_criterion_many(preds, gt_labels: torch.Tensor, ins_num: int):
+    """``ins_criterion`` for several predictions with the same labels (``[ins_coarse, ins_fine]`` of a training step,
+    train_dmsr.py:38-45) behind ONE wait for the device instead of one per prediction: a list of the 4-tuples
+    ``ins_criterion`` returns.  Falls back to separate calls where the fused kernels do not apply."""
+    preds = list(preds)
+    labels = gt_labels if gt_labels.dtype == torch.int64 else gt_labels.long()
+    ok = (len(preds) > 0 and all(p.dim() == 2 and p.shape == preds[0].shape and p.is_cuda for p in preds)
+          and preds[0].shape[1] == ins_num and 0 < preds[0].shape[0] == labels.shape[0] and ins_num <= 128)
+    if ok:
+        got = _InsCriterionFn.apply(labels.to(preds[0].device).contiguous(), ins_num, *preds)
+        if got[0] is not None:
+            return [tuple(got[4 * i: 4 * i + 4]) for i in range(len(preds))]
+    return [ins_criterion(p, gt_labels, ins_num) for p in preds]
 
 
 def ins_criterion(pred_ins: torch.Tensor, gt_labels: torch.Tensor, ins_num: int, reduce=None, fused: bool = True):
@@ -136,7 +164,7 @@ def ins_criterion(pred_ins: torch.Tensor, gt_labels: torch.Tensor, ins_num: int,
     if fused and reduce is None and n > 0 and ins_num <= 128 and pred_ins.is_cuda:
         # five launches instead of ~100 tensor operations (the host is the bottleneck of this part of a training step);
         # ``fused=False`` is the same arithmetic written with tensor operations (and the only form under ``reduce``)
-        got = _InsCriterionFn.apply(pred_ins, labels.to(pred_ins.device).contiguous(), ins_num)
+        got = _InsCriterionFn.apply(labels.to(pred_ins.device).contiguous(), ins_num, pred_ins)
         if got[0] is not None:
             return got
     if reduce is None:

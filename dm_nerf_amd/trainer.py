@@ -36,6 +36,19 @@ class _MseFn(torch.autograd.Function):
         return diff * (g * (2.0 / diff.numel())), None
 
 
+def instance_loss(gt_labels, ins_num: int, reduce=None) -> Callable:
+    """The ``ins_loss`` callable of ``train_step`` for ``dm_nerf_amd.ins_criterion`` on fixed labels: ``f(pred)`` is the loss
+    sum of one map, ``f.many([coarse, fine])`` evaluates both behind one wait for the device."""
+    from .evaluator import ins_criterion, ins_criterion_many
+
+    def one(pred):
+        return ins_criterion(pred, gt_labels, ins_num, reduce=reduce)[0]
+
+    if reduce is None:
+        one.many = lambda preds: [t[0] for t in ins_criterion_many(preds, gt_labels, ins_num)]
+    return one
+
+
 def make_optimizer(model_coarse, model_fine, lrate: float = 5e-4) -> torch.optim.Optimizer:
     """``Adam(coarse.parameters() + fine.parameters(), lr, betas=(0.9, 0.999))`` (train_dmsr.py:127-128)."""
     return torch.optim.Adam(list(model_coarse.parameters()) + list(model_fine.parameters()), lr=lrate,
@@ -69,7 +82,11 @@ def train_step(i: int, batch_rays, target_rgb, nerf, z_vals_coarse, optimizer, l
     total = (mse_f + mse_c) * share
     terms = {"rgb_coarse": mse_c, "rgb_fine": mse_f}
     if ins_loss is not None:                                                        # train_dmsr.py:38-45
-        terms["ins_coarse"], terms["ins_fine"] = ins_loss(out["ins_coarse"]), ins_loss(out["ins_fine"])
+        many = getattr(ins_loss, "many", None)       # both maps behind one wait for the device (evaluator.ins_criterion_many)
+        if many is not None:
+            terms["ins_coarse"], terms["ins_fine"] = many([out["ins_coarse"], out["ins_fine"]])
+        else:
+            terms["ins_coarse"], terms["ins_fine"] = ins_loss(out["ins_coarse"]), ins_loss(out["ins_fine"])
         total = total + terms["ins_coarse"] + terms["ins_fine"]
     if penalizer is not None:                                                       # train_dmsr.py:53-60
         terms["empty_coarse"] = penalizer(out["raw_coarse"], out["z_vals_coarse"], out["depth_coarse"])

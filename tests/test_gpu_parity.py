@@ -959,6 +959,21 @@ def test_fused_loss_head_equals_the_tensor_operation_form():
                 assert abs(a - b) <= 2e-6 * max(abs(b), 1e-3), (tag, vals)
             if len(grads) == 2:
                 np.testing.assert_allclose(grads[0], grads[1], rtol=2e-5, atol=2e-6 * np.abs(grads[1]).max(), err_msg=f"{tag} term {term}")
+    # two predictions behind one wait for the device: the same values and gradients as two calls
+    tag = "a"
+    n, ins_num, present, seed = cases.CRITERION_CASES[tag]
+    pred, labels = cases.criterion_case(n, ins_num, present, seed)
+    pred2 = np.ascontiguousarray(pred[::-1])
+    lab = torch.from_numpy(labels).to(DEV)
+    pa, pb = G(pred).requires_grad_(True), G(pred2).requires_grad_(True)
+    both = dm.ins_criterion_many([pa, pb], lab, ins_num)
+    (both[0][0] + 2.0 * both[1][3]).backward()
+    qa, qb = G(pred).requires_grad_(True), G(pred2).requires_grad_(True)
+    one_a, one_b = dm.ins_criterion(qa, lab, ins_num), dm.ins_criterion(qb, lab, ins_num)
+    (one_a[0] + 2.0 * one_b[3]).backward()
+    for got, want in zip(both[0] + both[1], one_a + one_b):
+        assert float(got.detach()) == float(want.detach())
+    assert torch.equal(pa.grad, qa.grad) and torch.equal(pb.grad, qb.grad)
     # labels beyond the fused kernels' table (>= 1024): same values through the fallback
     pred, labels = cases.criterion_case(*cases.CRITERION_CASES[next(iter(cases.CRITERION_CASES))])
     far = torch.from_numpy(labels).to(DEV) * 1000

@@ -81,6 +81,10 @@ def train_step(i: int, batch_rays, target_rgb, nerf, z_vals_coarse, optimizer, l
     share = 1.0 if shard is None else shard[0] / shard[1]          # mean over the batch = sum of share * mean over shard
     total = (mse_f + mse_c) * share
     terms = {"rgb_coarse": mse_c, "rgb_fine": mse_f}
+    empty = None
+    if penalizer is not None:       # issued first: its kernels run while the host waits for the instance head's cost matrices
+        empty = (penalizer(out["raw_coarse"], out["z_vals_coarse"], out["depth_coarse"]),
+                 penalizer(out["raw_fine"], out["z_vals_fine"], out["depth_fine"]))
     if ins_loss is not None:                                                        # train_dmsr.py:38-45
         many = getattr(ins_loss, "many", None)       # both maps behind one wait for the device (evaluator.ins_criterion_many)
         if many is not None:
@@ -88,9 +92,8 @@ def train_step(i: int, batch_rays, target_rgb, nerf, z_vals_coarse, optimizer, l
         else:
             terms["ins_coarse"], terms["ins_fine"] = ins_loss(out["ins_coarse"]), ins_loss(out["ins_fine"])
         total = total + terms["ins_coarse"] + terms["ins_fine"]
-    if penalizer is not None:                                                       # train_dmsr.py:53-60
-        terms["empty_coarse"] = penalizer(out["raw_coarse"], out["z_vals_coarse"], out["depth_coarse"])
-        terms["empty_fine"] = penalizer(out["raw_fine"], out["z_vals_fine"], out["depth_fine"])
+    if empty is not None:                                                           # train_dmsr.py:53-60 (summed in its order)
+        terms["empty_coarse"], terms["empty_fine"] = empty
         total = total + terms["empty_coarse"] + terms["empty_fine"]
     optimizer.zero_grad()
     total.backward()

@@ -74,7 +74,7 @@ struct EpiSplitSave {
       x0 = relu_bits(x0);
       x1 = relu_bits(x1);
     }
-    if (img != nullptr) {      // always taken in the saving kernel; the run-time test keeps the piece a unit (see above)
+    if (imgu != nullptr) {     // always taken in the saving kernel; the run-time (scalar) test keeps the piece a unit (see above)
       image_pair_store(imgu + 16 * t * 64, lane_bytes, q, x0, x1);
       if (RELU) {
         unsigned& w = msk[(16 * t + 2 * q) >> 5];
@@ -101,7 +101,7 @@ struct EpiRgbSave {
   unsigned lane_bytes = 0;
   __device__ __forceinline__ void operator()(int t, int q, float a0, float a1) const {
     const float x0 = relu_bits(a0), x1 = relu_bits(a1);
-    if (img != nullptr) {
+    if (imgu != nullptr) {
       image_pair_store(imgu + 16 * t * 64, lane_bytes, q, x0, x1);
       unsigned& w = msk[(16 * t + 2 * q) >> 5];
       sign_bit_or(w, x0, (16 * t + 2 * q) & 31);

@@ -761,6 +761,37 @@ def test_training_steps_reduce_loss_and_checkpoint_roundtrip(tmp_path):
     np.testing.assert_array_equal(H(a), H(b))
 
 
+def test_train_step_with_all_loss_heads_is_the_same_step_in_every_calling_form():
+    """The three ways of running a step with the instance and emptiness heads -- two ins_criterion calls (the reference's
+    form, train_dmsr.py:38-45), ``trainer.instance_loss(...).many`` (both maps behind one wait for the device) and
+    ``report=False`` (no read-back) -- give the same loss terms and leave bit-identical weights behind."""
+    from dm_nerf_amd import trainer
+    n = 192
+    o, d, _, _ = cases.path_rays(n, seed=23)
+    rays = G(np.stack([o, d], 0))
+    target = torch.full((n, 3), 0.4, device=DEV)
+    labels = torch.from_numpy(np.random.default_rng(5).integers(0, 13, size=n)).to(DEV)
+    z = dm.z_val_sample(n, cases.NEAR, cases.FAR, cases.N_SAMPLES)
+    results = []
+    for form in ("two_calls", "many", "no_report"):
+        pos, view, coarse, fine, args = nets(13, 0, 1)
+        coarse.train(); fine.train()
+        args.perturb, args.is_train, args.tolerance, args.deta_w = 1.0, True, 0.05, 0.05
+        opt = trainer.make_optimizer(coarse, fine, lrate=5e-4)
+        ins = (lambda pred: dm.ins_criterion(pred, labels, 13)[0]) if form == "two_calls" else trainer.instance_loss(labels, 13)
+        pen = lambda raw, zz, depth: dm.ins_penalizer(raw, zz, depth, rays[1], args)
+        torch.manual_seed(11)
+        rep = None
+        for i in range(2):
+            rep = trainer.train_step(i, rays, target, (pos, view, coarse, fine, args), z, opt, ins_loss=ins, penalizer=pen,
+                                     report=form != "no_report")
+        rep = {k: float(v) for k, v in rep.items() if k != "psnr_fine"}
+        results.append((rep, torch.cat([p.detach().reshape(-1) for p in list(coarse.parameters()) + list(fine.parameters())])))
+    for rep, w in results[1:]:
+        assert rep == results[0][0]
+        assert torch.equal(w, results[0][1])
+
+
 def test_fine_stage_gradients_on_golden_depths(golden):
     """Fine field + compositing backward at the reference's own resampled depths (sampler out of the loop)."""
     from dm_nerf_amd.autograd import FieldFn

@@ -72,6 +72,10 @@ def train_step(i: int, batch_rays, target_rgb, nerf, z_vals_coarse, optimizer, l
     (a SUM): the colour terms are weighted by the shard's share of the batch, the instance / emptiness terms see the
     whole batch's statistics, so the summed gradient is that of the unsharded loss for shards of any sizes.
 
+    ``ins_loss(pred) -> loss`` is called on the coarse and on the fine instance map (train_dmsr.py:38-45); if it has a
+    ``many`` attribute (``trainer.instance_loss`` builds such callables), ``ins_loss.many([coarse, fine])`` is called
+    instead and evaluates both behind one wait for the device.
+
     Returns the loss terms as floats (one device read-back), or with ``report=False`` as detached 0-dim tensors without
     waiting for the device."""
     position_embedder, view_embedder, model_coarse, model_fine, args = nerf

@@ -109,15 +109,16 @@ __global__ __launch_bounds__(1024) void ins_label_prep_kernel(const long* labels
   }
 }
 
-// the statistics without sorting the rays: workgroup v walks ALL class indices and adds up the rows of its own class, in
-// ray order (wave w owns the w-th quarter of the rays; the four partial sums are added in wave order): deterministic
+// the statistics without sorting the rays: workgroup (v, chunk) walks the class indices of its chunk of the rays and adds up
+// the rows of class v in ray order (wave w owns the w-th quarter of the chunk; partial sums are added in wave order, the
+// chunks' fp64 partials in chunk order by ins_cost_kernel): deterministic
 __global__ __launch_bounds__(256) void ins_stats_scan_kernel(const float* pred, const long* cls, long N, int K,
-                                                             float* stats /* [3][V][K] */, int V) {
+                                                             double* partial /* [chunks][3][V][K] */, int V) {
   __shared__ double part[4][3][kMaxCols];
   const int v = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long per = ((N + 255) / 256) * 64;          // rays per wave, whole groups of 64
-  const long begin = wave * per, end = begin + per < N ? begin + per : N;
+  const long per = ((N + 256L * gridDim.y - 1) / (256L * gridDim.y)) * 64;          // rays per wave, whole groups of 64
+  const long begin = ((long)blockIdx.y * 4 + wave) * per, end = begin + per < N ? begin + per : N;
   double s1[2] = {0.0, 0.0}, s0[2] = {0.0, 0.0}, tp[2] = {0.0, 0.0};
   for (long i0 = begin; i0 < end; i0 += 64) {
     const long i = i0 + lane;
@@ -147,17 +148,23 @@ __global__ __launch_bounds__(256) void ins_stats_scan_kernel(const float* pred, 
   __syncthreads();
   for (int e = threadIdx.x; e < 3 * K; e += 256) {
     const int q = e / K, p = e - q * K;
-    stats[((long)q * V + v) * K + p] = (float)(part[0][q][p] + part[1][q][p] + part[2][q][p] + part[3][q][p]);
+    partial[(((long)blockIdx.y * 3 + q) * V + v) * K + p] = part[0][q][p] + part[1][q][p] + part[2][q][p] + part[3][q][p];
   }
 }
 
 // cost matrices (evaluator.py:60-70) from the statistics; host_blob = {V, flag, cost_ce + cost_siou [Vmax][K]} is what
 // the host's Hungarian step reads back in one copy
-__global__ __launch_bounds__(256) void ins_cost_kernel(const float* stats, const float* count, const int* meta, long N,
-                                                       int K, int Vmax, float* cost /* [2][Vmax][K] */, float* colsum /* [2][K] */,
-                                                       float* host_blob) {
+__global__ __launch_bounds__(256) void ins_cost_kernel(const double* partial, int chunks, float* stats, const float* count,
+                                                       const int* meta, long N, int K, int Vmax, float* cost /* [2][Vmax][K] */,
+                                                       float* colsum /* [2][K] */, float* host_blob) {
   __shared__ float s0sum[kMaxCols], tpsum[kMaxCols];
   const int V = meta[0];
+  for (int e = threadIdx.x; e < 3 * Vmax * K; e += 256) {     // stats = sum of the chunks' partials, in chunk order
+    double v = 0.0;
+    for (int c = 0; c < chunks; ++c) v += partial[(long)c * 3 * Vmax * K + e];
+    stats[e] = (float)v;
+  }
+  __syncthreads();
   const float* s1 = stats;
   const float* s0 = stats + (long)Vmax * K;
   const float* tp = stats + 2L * Vmax * K;
@@ -275,22 +282,28 @@ extern "C" int dmn_ins_label_prep(const long* labels, long n_rays, int max_class
   return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
 }
 
+extern "C" int dmn_ins_stats_chunks(long n_rays) {      // ray chunks of dmn_ins_stats_scan: ~512 rays per workgroup
+  if (n_rays <= 0) return 1;
+  const long c = (n_rays + 511) / 512;
+  return (int)(c < 1 ? 1 : (c > 16 ? 16 : c));
+}
+
 extern "C" int dmn_ins_stats_scan(const float* pred, const long* classes, long n_rays, int n_cols, int n_classes,
-                                  float* stats, void* stream) {
+                                  double* partial, void* stream) {
   if (n_rays < 0 || n_cols <= 0 || n_classes <= 0) return DMN_ERR_BAD_ARG;
   if (n_cols > kMaxCols) return DMN_ERR_UNSUPPORTED;
-  if (!pred || !classes || !stats) return DMN_ERR_BAD_ARG;
-  hipLaunchKernelGGL(ins_stats_scan_kernel, dim3(n_classes), dim3(256), 0, (hipStream_t)stream, pred, classes, n_rays,
-                     n_cols, stats, n_classes);
+  if (!pred || !classes || !partial) return DMN_ERR_BAD_ARG;
+  hipLaunchKernelGGL(ins_stats_scan_kernel, dim3(n_classes, dmn_ins_stats_chunks(n_rays)), dim3(256), 0,
+                     (hipStream_t)stream, pred, classes, n_rays, n_cols, partial, n_classes);
   return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
 }
 
-extern "C" int dmn_ins_cost(const float* stats, const float* count, const int* meta, long n_rays, int n_cols,
-                            int max_classes, float* cost, float* colsum, float* host_blob, void* stream) {
+extern "C" int dmn_ins_cost(const double* partial, float* stats, const float* count, const int* meta, long n_rays,
+                            int n_cols, int max_classes, float* cost, float* colsum, float* host_blob, void* stream) {
   if (n_rays <= 0 || n_cols <= 0 || n_cols > kMaxCols || max_classes <= 0) return DMN_ERR_BAD_ARG;
-  if (!stats || !count || !meta || !cost || !colsum || !host_blob) return DMN_ERR_BAD_ARG;
-  hipLaunchKernelGGL(ins_cost_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stats, count, meta, n_rays, n_cols,
-                     max_classes, cost, colsum, host_blob);
+  if (!partial || !stats || !count || !meta || !cost || !colsum || !host_blob) return DMN_ERR_BAD_ARG;
+  hipLaunchKernelGGL(ins_cost_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, dmn_ins_stats_chunks(n_rays),
+                     stats, count, meta, n_rays, n_cols, max_classes, cost, colsum, host_blob);
   return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
 }
 

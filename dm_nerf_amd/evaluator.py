@@ -79,13 +79,14 @@ class _InsCriterionFn(torch.autograd.Function):
         classes, count, meta = _label_prep(labels, ins_num)
         m, stride = len(preds), 2 + ins_num * k
         stats = torch.empty(m, 3, ins_num, k, dtype=torch.float32, device=dev)
+        partial = torch.empty(m, lib.dmn_ins_stats_chunks(n), 3, ins_num, k, dtype=torch.float64, device=dev)
         cost = torch.empty(m, 2, ins_num, k, dtype=torch.float32, device=dev)
         colsum = torch.empty(m, 2, k, dtype=torch.float32, device=dev)
         blob = torch.empty(m, stride, dtype=torch.float32, device=dev)
         for i, pred in enumerate(preds):
-            check(lib.dmn_ins_stats_scan(ptr(pred), ptr(classes), n, k, ins_num, ptr(stats[i]), st), "dmn_ins_stats_scan")
-            check(lib.dmn_ins_cost(ptr(stats[i]), ptr(count), ptr(meta), n, k, ins_num, ptr(cost[i]), ptr(colsum[i]),
-                                   ptr(blob[i]), st), "dmn_ins_cost")
+            check(lib.dmn_ins_stats_scan(ptr(pred), ptr(classes), n, k, ins_num, ptr(partial[i]), st), "dmn_ins_stats_scan")
+            check(lib.dmn_ins_cost(ptr(partial[i]), ptr(stats[i]), ptr(count), ptr(meta), n, k, ins_num, ptr(cost[i]),
+                                   ptr(colsum[i]), ptr(blob[i]), st), "dmn_ins_cost")
         host = blob.cpu().numpy()                                                     # the one wait for the device
         v = int(host[0, 0])
         if host[0, 1] != 0.0 or v == 0:

@@ -225,17 +225,20 @@ int dmn_ins_stats_bwd(const float* pred, const long* classes, long n_rays, int n
  * reference: evaluator.py:42-52).  max_classes = ins_num (the reference's gt_ins has that many columns, :22).
  *   dmn_ins_label_prep  labels [N] int64 in [0, 1024) -> classes [N] (index of the label among the labels present, in
  *                       increasing order: torch.unique's inverse, :21,25), count [max_classes], meta {V, error flag}
- *   dmn_ins_stats_scan  the statistics above from classes [N] (no sorted order needed), stats [3][max_classes][n_cols]
- *   dmn_ins_cost        cost [2][max_classes][n_cols] (cost_ce, cost_siou; :60-67), colsum [2][n_cols] (column sums of
+ *   dmn_ins_stats_scan  fp64 partial statistics of dmn_ins_stats_chunks(N) ray chunks from classes [N] (no sorted order
+ *                       needed): partial [chunks][3][max_classes][n_cols]
+ *   dmn_ins_cost        stats [3][max_classes][n_cols] (the partials summed in chunk order), cost [2][max_classes][n_cols]
+ *                       (cost_ce, cost_siou; :60-67), colsum [2][n_cols] (column sums of
  *                       S0 and TP) and host_blob {V, flag, cost_ce + cost_siou [max_classes][n_cols]} for the host
  *   dmn_ins_loss        out4 = {sum, valid_ce, invalid_ce, valid_siou} (:27-37) for col_of [max_classes] / class_of [n_cols]
  *   dmn_ins_loss_bwd    g_stats [3][max_classes][n_cols] from the upstream gradients of the four outputs (NULL = 0) */
 int dmn_ins_label_prep(const long* labels, long n_rays, int max_classes, long* classes, float* count, int* meta,
                        void* stream);
-int dmn_ins_stats_scan(const float* pred, const long* classes, long n_rays, int n_cols, int n_classes, float* stats,
+int dmn_ins_stats_chunks(long n_rays);
+int dmn_ins_stats_scan(const float* pred, const long* classes, long n_rays, int n_cols, int n_classes, double* partial,
                        void* stream);
-int dmn_ins_cost(const float* stats, const float* count, const int* meta, long n_rays, int n_cols, int max_classes,
-                 float* cost, float* colsum, float* host_blob, void* stream);
+int dmn_ins_cost(const double* partial, float* stats, const float* count, const int* meta, long n_rays, int n_cols,
+                 int max_classes, float* cost, float* colsum, float* host_blob, void* stream);
 int dmn_ins_loss(const float* cost, const float* colsum, const int* col_of, const int* class_of, const int* meta,
                  long n_rays, int n_cols, int max_classes, float* out4, void* stream);
 int dmn_ins_loss_bwd(const float* stats, const float* count, const float* colsum, const int* class_of, const int* meta,

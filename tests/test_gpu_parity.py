@@ -1005,6 +1005,22 @@ def test_fused_loss_head_equals_the_tensor_operation_form():
     for got, want in zip(both[0] + both[1], one_a + one_b):
         assert float(got.detach()) == float(want.detach())
     assert torch.equal(pa.grad, qa.grad) and torch.equal(pb.grad, qb.grad)
+    # training-size batches: several ray chunks per class in the statistics kernel, label histogram over many passes
+    for n, ins_num, present in ((5000, 13, (0, 1, 2, 5, 7, 11, 12)), (4096, 93, tuple(range(0, 93, 3))), (1237, 40, (3, 39))):
+        rng = np.random.default_rng(n)
+        labels = rng.choice(np.asarray(present), size=n).astype(np.int64)
+        pred = rng.uniform(0.01, 0.99, size=(n, ins_num)).astype(np.float32)
+        lab = torch.from_numpy(labels).to(DEV)
+        vals, grads = [], []
+        for fused in (True, False):
+            p = G(pred).requires_grad_(True)
+            out = dm.ins_criterion(p, lab, ins_num, fused=fused)
+            out[0].backward()
+            vals.append([float(o.detach()) for o in out])
+            grads.append(H(p.grad))
+        for a, b in zip(*vals):
+            assert abs(a - b) <= 2e-6 * max(abs(b), 1e-3), (n, vals)
+        np.testing.assert_allclose(grads[0], grads[1], rtol=2e-5, atol=2e-6 * np.abs(grads[1]).max())
     # labels beyond the fused kernels' table (>= 1024): same values through the fallback
     pred, labels = cases.criterion_case(*cases.CRITERION_CASES[next(iter(cases.CRITERION_CASES))])
     far = torch.from_numpy(labels).to(DEV) * 1000

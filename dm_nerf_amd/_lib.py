@@ -75,11 +75,14 @@ SIGNATURES = {
     "dmn_ins_stats_fwd": (c_int, [_P, _P, _P, c_long, c_int, c_int, _P, _P]),
     "dmn_ins_stats_bwd": (c_int, [_P, _P, c_long, c_int, c_int, _P, _P, _P]),
     "dmn_ins_label_prep": (c_int, [_P, c_long, c_int, _P, _P, _P, _P]),
+    "dmn_ins_label_hist": (c_int, [_P, c_long, c_int, _P, _P, _P]),
+    "dmn_ins_label_slots": (c_int, [_P, c_long, _P, c_int, c_int, _P, _P, _P, _P]),
+    "dmn_ins_stats_sum": (c_int, [_P, c_long, c_int, c_int, _P, _P]),
     "dmn_ins_stats_chunks": (c_int, [c_long]),
     "dmn_ins_stats_scan": (c_int, [_P, _P, c_long, c_int, c_int, _P, _P]),
-    "dmn_ins_cost": (c_int, [_P, _P, _P, _P, c_long, c_int, c_int, _P, _P, _P, _P]),
-    "dmn_ins_loss": (c_int, [_P, _P, _P, _P, _P, c_long, c_int, c_int, _P, _P]),
-    "dmn_ins_loss_bwd": (c_int, [_P, _P, _P, _P, _P, c_long, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "dmn_ins_cost": (c_int, [_P, _P, _P, _P, c_long, _P, c_int, c_int, _P, _P, _P, _P]),
+    "dmn_ins_loss": (c_int, [_P, _P, _P, _P, _P, c_long, _P, c_int, c_int, _P, _P]),
+    "dmn_ins_loss_bwd": (c_int, [_P, _P, _P, _P, _P, c_long, _P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "dmn_composite_fwd": (c_int, [_P, _P, c_long, _P, c_long, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "dmn_composite_bwd": (c_int, [_P, _P, c_long, _P, _P, _P, _P, _P, _P, c_long, c_int, c_int, c_int, _P, _P]),
     "dmn_sample_pdf": (c_int, [_P, c_long, _P, c_long, _P, c_long, c_long, c_int, c_int, _P, _P]),

@@ -67,20 +67,33 @@ __global__ void ins_stats_bwd_kernel(const float* pred, const long* cls, long N,
 // class indices 0 .. V-1 (what torch.unique's inverse gives), count[v] = rays of class v.  meta = {V, error flag}.
 constexpr int kMaxLabel = 1024;
 
+// Ray-sharded training (bins > 0): the label set is the whole batch's.  hist_out != null: only this shard's histogram
+// over labels [0, bins) leaves (as floats, to be summed over the shards); hist_in != null: the classes come from that
+// summed histogram instead of this shard's own.
 __global__ __launch_bounds__(1024) void ins_label_prep_kernel(const long* labels, long N, int Vmax, long* classes,
-                                                              float* count, int* meta) {
+                                                              float* count, int* meta, const float* hist_in,
+                                                              float* hist_out, int bins) {
   __shared__ int hist[kMaxLabel];
   __shared__ int slot[kMaxLabel];
   __shared__ int bad;
   const int tid = threadIdx.x;
-  hist[tid] = 0;
+  const int limit = bins > 0 ? bins : kMaxLabel;
+  hist[tid] = hist_in != nullptr && tid < bins ? (int)hist_in[tid] : 0;
   if (tid == 0) bad = 0;
   __syncthreads();
   for (long i = tid; i < N; i += 1024) {
     const long l = labels[i];
-    if (l < 0 || l >= kMaxLabel) bad = 1; else atomicAdd(&hist[l], 1);
+    if (l < 0 || l >= limit) bad = 1; else if (hist_in == nullptr) atomicAdd(&hist[l], 1);
   }
   __syncthreads();
+  if (hist_out != nullptr) {
+    if (tid < bins) hist_out[tid] = (float)hist[tid];
+    if (tid == 0) {
+      meta[0] = 0;
+      meta[1] = bad;
+    }
+    return;
+  }
   // exclusive prefix count of the non-empty bins (Hillis-Steele over 1024 flags)
   const int mine = hist[tid] > 0 ? 1 : 0;
   slot[tid] = mine;
@@ -105,7 +118,7 @@ __global__ __launch_bounds__(1024) void ins_label_prep_kernel(const long* labels
   }
   for (long i = tid; i < N; i += 1024) {
     const long l = labels[i];
-    classes[i] = (fail || l < 0 || l >= kMaxLabel) ? 0 : slot[l];
+    classes[i] = (fail || l < 0 || l >= limit) ? 0 : slot[l];
   }
 }
 
@@ -152,18 +165,30 @@ __global__ __launch_bounds__(256) void ins_stats_scan_kernel(const float* pred, 
   }
 }
 
+__global__ void ins_stats_sum_kernel(const double* partial, int chunks, long elems, float* stats) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= elems) return;
+  double v = 0.0;
+  for (int c = 0; c < chunks; ++c) v += partial[(long)c * elems + e];
+  stats[e] = (float)v;
+}
+
 // cost matrices (evaluator.py:60-70) from the statistics; host_blob = {V, flag, cost_ce + cost_siou [Vmax][K]} is what
 // the host's Hungarian step reads back in one copy
+// partial == null: stats is complete already (ray-sharded training: summed over the shards in between); n_dev != null: the
+// ray count of the whole batch, on the device
 __global__ __launch_bounds__(256) void ins_cost_kernel(const double* partial, int chunks, float* stats, const float* count,
-                                                       const int* meta, long N, int K, int Vmax, float* cost /* [2][Vmax][K] */,
-                                                       float* colsum /* [2][K] */, float* host_blob) {
+                                                       const int* meta, long N, const float* n_dev, int K, int Vmax,
+                                                       float* cost /* [2][Vmax][K] */, float* colsum /* [2][K] */,
+                                                       float* host_blob) {
   __shared__ float s0sum[kMaxCols], tpsum[kMaxCols];
   const int V = meta[0];
-  for (int e = threadIdx.x; e < 3 * Vmax * K; e += 256) {     // stats = sum of the chunks' partials, in chunk order
-    double v = 0.0;
-    for (int c = 0; c < chunks; ++c) v += partial[(long)c * 3 * Vmax * K + e];
-    stats[e] = (float)v;
-  }
+  if (partial != nullptr)
+    for (int e = threadIdx.x; e < 3 * Vmax * K; e += 256) {     // stats = sum of the chunks' partials, in chunk order
+      double v = 0.0;
+      for (int c = 0; c < chunks; ++c) v += partial[(long)c * 3 * Vmax * K + e];
+      stats[e] = (float)v;
+    }
   __syncthreads();
   const float* s1 = stats;
   const float* s0 = stats + (long)Vmax * K;
@@ -184,7 +209,7 @@ __global__ __launch_bounds__(256) void ins_cost_kernel(const double* partial, in
     host_blob[0] = (float)V;
     host_blob[1] = (float)meta[1];
   }
-  const float n = (float)N;
+  const float n = n_dev != nullptr ? *n_dev : (float)N;
   for (int e = threadIdx.x; e < Vmax * K; e += 256) {
     const int v = e / K, k = e - v * K;
     float ce = 0.f, siou = 0.f;
@@ -203,8 +228,8 @@ __global__ __launch_bounds__(256) void ins_cost_kernel(const double* partial, in
 // loss terms for a matching: col_of[v] = column matched to class v (v < V), class_of[k] = class matched to column k or -1
 // out = {valid_ce + invalid_ce + valid_siou, valid_ce, invalid_ce, valid_siou} (evaluator.py:27-37)
 __global__ __launch_bounds__(64) void ins_loss_kernel(const float* cost, const float* colsum, const int* col_of,
-                                                      const int* class_of, const int* meta, long N, int K, int Vmax,
-                                                      float* out) {
+                                                      const int* class_of, const int* meta, long N, const float* n_dev,
+                                                      int K, int Vmax, float* out) {
   const int V = meta[0];
   const int lane = threadIdx.x;
   float ce = 0.f, siou = 0.f, inv = 0.f;
@@ -226,7 +251,8 @@ __global__ __launch_bounds__(64) void ins_loss_kernel(const float* cost, const f
   }
   if (lane == 0) {
     const float valid_ce = ce / (float)V, valid_siou = siou / (float)V;
-    const float invalid_ce = unmatched ? inv / ((float)N * (float)unmatched) : 0.f;
+    const float n = n_dev != nullptr ? *n_dev : (float)N;
+    const float invalid_ce = unmatched ? inv / (n * (float)unmatched) : 0.f;
     out[0] = valid_ce + invalid_ce + valid_siou;
     out[1] = valid_ce;
     out[2] = invalid_ce;
@@ -236,9 +262,10 @@ __global__ __launch_bounds__(64) void ins_loss_kernel(const float* cost, const f
 
 // d out / d stats for upstream gradients g[4] (null = 0) of the four outputs
 __global__ __launch_bounds__(256) void ins_loss_bwd_kernel(const float* stats, const float* count, const float* colsum,
-                                                           const int* class_of, const int* meta, long N, int K, int Vmax,
-                                                           const float* g_total, const float* g_ce, const float* g_inv,
-                                                           const float* g_siou, float* g_stats) {
+                                                           const int* class_of, const int* meta, long N,
+                                                           const float* n_dev, int K, int Vmax, const float* g_total,
+                                                           const float* g_ce, const float* g_inv, const float* g_siou,
+                                                           float* g_stats) {
   __shared__ int n_unmatched;
   const int V = meta[0];
   if (threadIdx.x == 0) {
@@ -249,7 +276,7 @@ __global__ __launch_bounds__(256) void ins_loss_bwd_kernel(const float* stats, c
   __syncthreads();
   const float gt = g_total ? *g_total : 0.f;
   const float a = gt + (g_ce ? *g_ce : 0.f), b = gt + (g_inv ? *g_inv : 0.f), s = gt + (g_siou ? *g_siou : 0.f);
-  const float n = (float)N, fv = (float)V;
+  const float n = n_dev != nullptr ? *n_dev : (float)N, fv = (float)V;
   const float* tp = stats + 2L * Vmax * K;
   for (int e = threadIdx.x; e < Vmax * K; e += 256) {
     const int v = e / K, k = e - v * K;
@@ -278,7 +305,34 @@ extern "C" int dmn_ins_label_prep(const long* labels, long n_rays, int max_class
   if (n_rays <= 0 || max_classes <= 0 || max_classes > kMaxCols) return DMN_ERR_BAD_ARG;
   if (!labels || !classes || !count || !meta) return DMN_ERR_BAD_ARG;
   hipLaunchKernelGGL(ins_label_prep_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, labels, n_rays, max_classes,
-                     classes, count, meta);
+                     classes, count, meta, (const float*)nullptr, (float*)nullptr, 0);
+  return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
+}
+
+extern "C" int dmn_ins_label_hist(const long* labels, long n_rays, int bins, float* hist, int* meta, void* stream) {
+  if (n_rays < 0 || bins <= 0 || bins > kMaxLabel) return DMN_ERR_BAD_ARG;
+  if (!labels || !hist || !meta) return DMN_ERR_BAD_ARG;
+  hipLaunchKernelGGL(ins_label_prep_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, labels, n_rays, 0,
+                     (long*)nullptr, (float*)nullptr, meta, (const float*)nullptr, hist, bins);
+  return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
+}
+
+extern "C" int dmn_ins_label_slots(const long* labels, long n_rays, const float* hist, int bins, int max_classes,
+                                   long* classes, float* count, int* meta, void* stream) {
+  if (n_rays < 0 || bins <= 0 || bins > kMaxLabel || max_classes <= 0 || max_classes > kMaxCols) return DMN_ERR_BAD_ARG;
+  if (!labels || !hist || !classes || !count || !meta) return DMN_ERR_BAD_ARG;
+  hipLaunchKernelGGL(ins_label_prep_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, labels, n_rays, max_classes,
+                     classes, count, meta, hist, (float*)nullptr, bins);
+  return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
+}
+
+extern "C" int dmn_ins_stats_sum(const double* partial, long n_rays, int n_cols, int max_classes, float* stats,
+                                 void* stream) {
+  if (n_rays < 0 || n_cols <= 0 || max_classes <= 0) return DMN_ERR_BAD_ARG;
+  if (!partial || !stats) return DMN_ERR_BAD_ARG;
+  const long elems = 3L * max_classes * n_cols;
+  hipLaunchKernelGGL(ins_stats_sum_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     partial, dmn_ins_stats_chunks(n_rays), elems, stats);
   return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
 }
 
@@ -299,31 +353,33 @@ extern "C" int dmn_ins_stats_scan(const float* pred, const long* classes, long n
 }
 
 extern "C" int dmn_ins_cost(const double* partial, float* stats, const float* count, const int* meta, long n_rays,
-                            int n_cols, int max_classes, float* cost, float* colsum, float* host_blob, void* stream) {
-  if (n_rays <= 0 || n_cols <= 0 || n_cols > kMaxCols || max_classes <= 0) return DMN_ERR_BAD_ARG;
-  if (!partial || !stats || !count || !meta || !cost || !colsum || !host_blob) return DMN_ERR_BAD_ARG;
+                            const float* n_rays_dev, int n_cols, int max_classes, float* cost, float* colsum,
+                            float* host_blob, void* stream) {
+  if (n_rays < 0 || (n_rays == 0 && !n_rays_dev) || n_cols <= 0 || n_cols > kMaxCols || max_classes <= 0) return DMN_ERR_BAD_ARG;
+  if (!stats || !count || !meta || !cost || !colsum || !host_blob) return DMN_ERR_BAD_ARG;
   hipLaunchKernelGGL(ins_cost_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, dmn_ins_stats_chunks(n_rays),
-                     stats, count, meta, n_rays, n_cols, max_classes, cost, colsum, host_blob);
+                     stats, count, meta, n_rays, n_rays_dev, n_cols, max_classes, cost, colsum, host_blob);
   return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
 }
 
 extern "C" int dmn_ins_loss(const float* cost, const float* colsum, const int* col_of, const int* class_of,
-                            const int* meta, long n_rays, int n_cols, int max_classes, float* out4, void* stream) {
-  if (n_rays <= 0 || n_cols <= 0 || n_cols > kMaxCols || max_classes <= 0) return DMN_ERR_BAD_ARG;
+                            const int* meta, long n_rays, const float* n_rays_dev, int n_cols, int max_classes,
+                            float* out4, void* stream) {
+  if (n_rays < 0 || (n_rays == 0 && !n_rays_dev) || n_cols <= 0 || n_cols > kMaxCols || max_classes <= 0) return DMN_ERR_BAD_ARG;
   if (!cost || !colsum || !col_of || !class_of || !meta || !out4) return DMN_ERR_BAD_ARG;
   hipLaunchKernelGGL(ins_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, cost, colsum, col_of, class_of, meta,
-                     n_rays, n_cols, max_classes, out4);
+                     n_rays, n_rays_dev, n_cols, max_classes, out4);
   return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
 }
 
 extern "C" int dmn_ins_loss_bwd(const float* stats, const float* count, const float* colsum, const int* class_of,
-                                const int* meta, long n_rays, int n_cols, int max_classes, const float* g_total,
-                                const float* g_ce, const float* g_inv, const float* g_siou, float* g_stats,
-                                void* stream) {
-  if (n_rays <= 0 || n_cols <= 0 || n_cols > kMaxCols || max_classes <= 0) return DMN_ERR_BAD_ARG;
+                                const int* meta, long n_rays, const float* n_rays_dev, int n_cols, int max_classes,
+                                const float* g_total, const float* g_ce, const float* g_inv, const float* g_siou,
+                                float* g_stats, void* stream) {
+  if (n_rays < 0 || (n_rays == 0 && !n_rays_dev) || n_cols <= 0 || n_cols > kMaxCols || max_classes <= 0) return DMN_ERR_BAD_ARG;
   if (!stats || !count || !colsum || !class_of || !meta || !g_stats) return DMN_ERR_BAD_ARG;
   hipLaunchKernelGGL(ins_loss_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stats, count, colsum, class_of,
-                     meta, n_rays, n_cols, max_classes, g_total, g_ce, g_inv, g_siou, g_stats);
+                     meta, n_rays, n_rays_dev, n_cols, max_classes, g_total, g_ce, g_inv, g_siou, g_stats);
   return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
 }
 

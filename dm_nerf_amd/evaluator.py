@@ -70,13 +70,25 @@ class _InsCriterionFn(torch.autograd.Function):
     columns): the caller falls back to the tensor-operation path."""
 
     @staticmethod
-    def forward(ctx, labels, ins_num, *preds):
+    def forward(ctx, labels, ins_num, reduce, *preds):
         from scipy.optimize import linear_sum_assignment
         lib = load()
         preds = [ops._dev(p, "pred_ins").contiguous() for p in preds]
         n, k = preds[0].shape
         dev, st = preds[0].device, current_stream()
-        classes, count, meta = _label_prep(labels, ins_num)
+        n_dev = None
+        if reduce is None:
+            classes, count, meta = _label_prep(labels, ins_num)
+        else:       # ray-sharded: label set, class counts and ray count of ALL shards (torch.unique over the whole batch)
+            classes = torch.empty(n, dtype=torch.int64, device=dev)
+            count = torch.empty(ins_num, dtype=torch.float32, device=dev)
+            meta = torch.empty(2, dtype=torch.int32, device=dev)
+            hist = torch.empty(ins_num + 1, dtype=torch.float32, device=dev)
+            check(lib.dmn_ins_label_hist(ptr(labels), n, ins_num + 1, ptr(hist), ptr(meta), st), "dmn_ins_label_hist")
+            hist = reduce("ins_label_count", hist).contiguous()
+            check(lib.dmn_ins_label_slots(ptr(labels), n, ptr(hist), ins_num + 1, ins_num, ptr(classes), ptr(count),
+                                          ptr(meta), st), "dmn_ins_label_slots")
+            n_dev = reduce("ins_ray_count", torch.full((1,), float(n), dtype=torch.float32, device=dev)).contiguous()
         m, stride = len(preds), 2 + ins_num * k
         stats = torch.empty(m, 3, ins_num, k, dtype=torch.float32, device=dev)
         partial = torch.empty(m, lib.dmn_ins_stats_chunks(n), 3, ins_num, k, dtype=torch.float64, device=dev)
@@ -85,8 +97,13 @@ class _InsCriterionFn(torch.autograd.Function):
         blob = torch.empty(m, stride, dtype=torch.float32, device=dev)
         for i, pred in enumerate(preds):
             check(lib.dmn_ins_stats_scan(ptr(pred), ptr(classes), n, k, ins_num, ptr(partial[i]), st), "dmn_ins_stats_scan")
-            check(lib.dmn_ins_cost(ptr(partial[i]), ptr(stats[i]), ptr(count), ptr(meta), n, k, ins_num, ptr(cost[i]),
-                                   ptr(colsum[i]), ptr(blob[i]), st), "dmn_ins_cost")
+            if reduce is not None:
+                check(lib.dmn_ins_stats_sum(ptr(partial[i]), n, k, ins_num, ptr(stats[i]), st), "dmn_ins_stats_sum")
+        if reduce is not None:      # the [3, V, K] statistics of all shards (evaluator.py:60-70 see the whole batch)
+            stats = reduce("ins_class_stats", stats).contiguous()
+        for i in range(m):
+            check(lib.dmn_ins_cost(None if reduce is not None else ptr(partial[i]), ptr(stats[i]), ptr(count), ptr(meta), n,
+                                   ptr(n_dev), k, ins_num, ptr(cost[i]), ptr(colsum[i]), ptr(blob[i]), st), "dmn_ins_cost")
         host = blob.cpu().numpy()                                                     # the one wait for the device
         v = int(host[0, 0])
         if host[0, 1] != 0.0 or v == 0:
@@ -100,9 +117,9 @@ class _InsCriterionFn(torch.autograd.Function):
         out = torch.empty(m, 4, dtype=torch.float32, device=dev)
         for i in range(m):
             check(lib.dmn_ins_loss(ptr(cost[i]), ptr(colsum[i]), ptr(match_t[i]), ptr(match_t[i]) + 4 * ins_num, ptr(meta),
-                                   n, k, ins_num, ptr(out[i]), st), "dmn_ins_loss")
+                                   n, ptr(n_dev), k, ins_num, ptr(out[i]), st), "dmn_ins_loss")
         ctx.save_for_backward(classes, stats, count, colsum, match_t, meta, *preds)
-        ctx.ins_num = ins_num
+        ctx.ins_num, ctx.n_dev = ins_num, n_dev
         ctx.set_materialize_grads(False)               # terms nobody differentiates arrive as None, not as zero tensors
         return tuple(out[i, j] for i in range(m) for j in range(4))      # outputs of this node: no select nodes behind them
 
@@ -120,16 +137,16 @@ class _InsCriterionFn(torch.autograd.Function):
             g = [None if t is None else t.reshape(1).float().contiguous() for t in g4]
             g_stats = torch.empty_like(stats[i])
             check(lib.dmn_ins_loss_bwd(ptr(stats[i]), ptr(count), ptr(colsum[i]), ptr(match_t[i]) + 4 * ctx.ins_num,
-                                       ptr(meta), n, k, ctx.ins_num, ptr(g[0]), ptr(g[1]), ptr(g[2]), ptr(g[3]),
-                                       ptr(g_stats), st), "dmn_ins_loss_bwd")
+                                       ptr(meta), n, ptr(ctx.n_dev), k, ctx.ins_num, ptr(g[0]), ptr(g[1]), ptr(g[2]),
+                                       ptr(g[3]), ptr(g_stats), st), "dmn_ins_loss_bwd")
             g_pred = torch.empty_like(pred)
             check(lib.dmn_ins_stats_bwd(ptr(pred), ptr(classes), n, k, ctx.ins_num, ptr(g_stats), ptr(g_pred), st),
                   "dmn_ins_stats_bwd")
             g_preds.append(g_pred)
-        return (None, None, *g_preds)
+        return (None, None, None, *g_preds)
 
 
-def ins_criterion_many(preds, gt_labels: torch.Tensor, ins_num: int):
+def ins_criterion_many(preds, gt_labels: torch.Tensor, ins_num: int, reduce=None):
     """``ins_criterion`` for several predictions with the same labels (``[ins_coarse, ins_fine]`` of a training step,
     train_dmsr.py:38-45) behind ONE wait for the device instead of one per prediction: a list of the 4-tuples
     ``ins_criterion`` returns.  Falls back to separate calls where the fused kernels do not apply."""
@@ -138,10 +155,10 @@ def ins_criterion_many(preds, gt_labels: torch.Tensor, ins_num: int):
     ok = (len(preds) > 0 and all(p.dim() == 2 and p.shape == preds[0].shape and p.is_cuda for p in preds)
           and preds[0].shape[1] == ins_num and 0 < preds[0].shape[0] == labels.shape[0] and ins_num <= 128)
     if ok:
-        got = _InsCriterionFn.apply(labels.to(preds[0].device).contiguous(), ins_num, *preds)
+        got = _InsCriterionFn.apply(labels.to(preds[0].device).contiguous(), ins_num, reduce, *preds)
         if got[0] is not None:
             return [tuple(got[4 * i: 4 * i + 4]) for i in range(len(preds))]
-    return [ins_criterion(p, gt_labels, ins_num) for p in preds]
+    return [ins_criterion(p, gt_labels, ins_num, reduce=reduce) for p in preds]
 
 
 def ins_criterion(pred_ins: torch.Tensor, gt_labels: torch.Tensor, ins_num: int, reduce=None, fused: bool = True):
@@ -154,18 +171,19 @@ def ins_criterion(pred_ins: torch.Tensor, gt_labels: torch.Tensor, ins_num: int,
     Matching and normalisation then see the whole batch (evaluator.py:21,60-70), every rank computes the same loss
     value, and its backward reaches the rank's own rays only -- so gradients must be SUMMED over ranks.
 
-    Without ``reduce`` the loss head runs as fused kernels (``csrc/ins_stats.hip``: label classes, class statistics,
-    cost matrices, loss terms and their gradient), with the Hungarian step on the host in between."""
+    The loss head runs as fused kernels (``csrc/ins_stats.hip``: label classes, class statistics, cost matrices, loss
+    terms and their gradient; under ``reduce`` with the three all-reduces in between), with the Hungarian step on the host;
+    ``fused=False`` is the same arithmetic in tensor operations."""
     from scipy.optimize import linear_sum_assignment
 
     if pred_ins.dim() != 2 or pred_ins.shape[1] != ins_num or gt_labels.shape[0] != pred_ins.shape[0]:
         raise ValueError("pred_ins must be [N, ins_num] and gt_labels [N]")
     n = pred_ins.shape[0]
     labels = gt_labels if gt_labels.dtype == torch.int64 else gt_labels.long()
-    if fused and reduce is None and n > 0 and ins_num <= 128 and pred_ins.is_cuda:
+    if fused and n > 0 and ins_num <= 128 and pred_ins.is_cuda:
         # five launches instead of ~100 tensor operations (the host is the bottleneck of this part of a training step);
-        # ``fused=False`` is the same arithmetic written with tensor operations (and the only form under ``reduce``)
-        got = _InsCriterionFn.apply(labels.to(pred_ins.device).contiguous(), ins_num, pred_ins)
+        # ``fused=False`` is the same arithmetic written with tensor operations
+        got = _InsCriterionFn.apply(labels.to(pred_ins.device).contiguous(), ins_num, reduce, pred_ins)
         if got[0] is not None:
             return got
     if reduce is None:

@@ -44,8 +44,7 @@ def instance_loss(gt_labels, ins_num: int, reduce=None) -> Callable:
     def one(pred):
         return ins_criterion(pred, gt_labels, ins_num, reduce=reduce)[0]
 
-    if reduce is None:
-        one.many = lambda preds: [t[0] for t in ins_criterion_many(preds, gt_labels, ins_num)]
+    one.many = lambda preds: [t[0] for t in ins_criterion_many(preds, gt_labels, ins_num, reduce=reduce)]
     return one
 
 

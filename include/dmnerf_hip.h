@@ -231,19 +231,28 @@ int dmn_ins_stats_bwd(const float* pred, const long* classes, long n_rays, int n
  *                       (cost_ce, cost_siou; :60-67), colsum [2][n_cols] (column sums of
  *                       S0 and TP) and host_blob {V, flag, cost_ce + cost_siou [max_classes][n_cols]} for the host
  *   dmn_ins_loss        out4 = {sum, valid_ce, invalid_ce, valid_siou} (:27-37) for col_of [max_classes] / class_of [n_cols]
- *   dmn_ins_loss_bwd    g_stats [3][max_classes][n_cols] from the upstream gradients of the four outputs (NULL = 0) */
+ *   dmn_ins_loss_bwd    g_stats [3][max_classes][n_cols] from the upstream gradients of the four outputs (NULL = 0)
+ * Ray-sharded training (the label set, the statistics and the ray count are the whole batch's; the caller sums them over
+ * the shards between the calls): dmn_ins_label_hist (this shard's histogram over labels [0, bins) as floats),
+ * dmn_ins_label_slots (classes / counts from the summed histogram), dmn_ins_stats_sum (partial -> stats, then
+ * dmn_ins_cost with partial = NULL), n_rays_dev = the summed ray count on the device (NULL: n_rays).              */
 int dmn_ins_label_prep(const long* labels, long n_rays, int max_classes, long* classes, float* count, int* meta,
                        void* stream);
+int dmn_ins_label_hist(const long* labels, long n_rays, int bins, float* hist, int* meta, void* stream);
+int dmn_ins_label_slots(const long* labels, long n_rays, const float* hist, int bins, int max_classes, long* classes,
+                        float* count, int* meta, void* stream);
+int dmn_ins_stats_sum(const double* partial, long n_rays, int n_cols, int max_classes, float* stats, void* stream);
 int dmn_ins_stats_chunks(long n_rays);
 int dmn_ins_stats_scan(const float* pred, const long* classes, long n_rays, int n_cols, int n_classes, double* partial,
                        void* stream);
-int dmn_ins_cost(const double* partial, float* stats, const float* count, const int* meta, long n_rays, int n_cols,
-                 int max_classes, float* cost, float* colsum, float* host_blob, void* stream);
+int dmn_ins_cost(const double* partial, float* stats, const float* count, const int* meta, long n_rays,
+                 const float* n_rays_dev, int n_cols, int max_classes, float* cost, float* colsum, float* host_blob,
+                 void* stream);
 int dmn_ins_loss(const float* cost, const float* colsum, const int* col_of, const int* class_of, const int* meta,
-                 long n_rays, int n_cols, int max_classes, float* out4, void* stream);
+                 long n_rays, const float* n_rays_dev, int n_cols, int max_classes, float* out4, void* stream);
 int dmn_ins_loss_bwd(const float* stats, const float* count, const float* colsum, const int* class_of, const int* meta,
-                     long n_rays, int n_cols, int max_classes, const float* g_total, const float* g_ce,
-                     const float* g_inv, const float* g_siou, float* g_stats, void* stream);
+                     long n_rays, const float* n_rays_dev, int n_cols, int max_classes, const float* g_total,
+                     const float* g_ce, const float* g_inv, const float* g_siou, float* g_stats, void* stream);
 
 /* ---- render_train (networks/render.py:6-28) / manipulator_render (manipulator.py:86-105) --
  * raw [N,S,C], z (stride), rays_d [N,3] -> rgb [N,3], weights [N,S], depth [N],

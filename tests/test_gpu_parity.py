@@ -1049,8 +1049,10 @@ class _TwoShardReducer:
         return t + rec
 
 
-def test_sharded_loss_heads_reproduce_the_unsharded_loss_and_gradient():
-    """ins_criterion and ins_penalizer on two unequal ray shards with their batch statistics summed (what
+@pytest.mark.parametrize("fused", [True, False])
+def test_sharded_loss_heads_reproduce_the_unsharded_loss_and_gradient(fused):
+    """(With the instance head as kernels -- histogram, statistics and ray count summed between the launches -- and in
+    its tensor-operation form.)  ins_criterion and ins_penalizer on two unequal ray shards with their batch statistics summed (what
     parallel.ShardReducer's all-reduce does): every shard computes the unsharded loss VALUE, and the shards' gradients
     together are the unsharded gradient -- the Hungarian matching sees the whole batch's cost matrices and the label
     set of the whole batch (one label occurs in shard B only), the penalizer the whole batch's mask sums."""
@@ -1065,10 +1067,10 @@ def test_sharded_loss_heads_reproduce_the_unsharded_loss_and_gradient():
     def losses(sl, reduce):
         p = G(pred[sl]).requires_grad_(True)
         r = G(raw[sl]).requires_grad_(True)
-        ins = dm.ins_criterion(p, lab[sl], ins_num, reduce=reduce)[0]
+        ins = dm.ins_criterion(p, lab[sl], ins_num, reduce=reduce, fused=fused)[0]
         pen = dm.ins_penalizer(r, G(z[sl]), G(depth[sl]), G(d[sl]), pargs, reduce=reduce)
         (ins + pen).backward()
-        return float(ins), float(pen), H(p.grad), H(r.grad)
+        return float(ins.detach()), float(pen.detach()), H(p.grad), H(r.grad)
 
     whole = losses(slice(0, n), None)
     shards = (slice(0, cut), slice(cut, n))

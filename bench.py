@@ -354,6 +354,11 @@ def main():
         if meas is not None:                # measured at exactly this launch size (rays per launch, S mix, C)
             out["roofline_composite"]["traffic"] = meas["hbm_bytes_per_launch"]
             out["roofline_composite"]["traffic_source"] = meas["source"]
+        meas = json.load(open(traffic_file)).get(f"{ns.workload}_chunk{ns.chunk}_field_{ns.precision}")
+        if meas is not None and INS_NUM == 13:      # the headline kernel's own HBM bytes per (average) launch
+            out["roofline"]["traffic"] = meas["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = meas["source"]
+            out["roofline"]["algorithmic_bytes_per_launch"] = meas["algorithmic_bytes_per_launch"]
 
     # ---- beside the headline (N = 1 only, outside its timed region): the split-precision modes over the same --steps
     modes = [m for m in ns.split_modes.split(",") if m and m != ns.precision] if world == 1 and not ns.no_split else []

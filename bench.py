@@ -97,7 +97,9 @@ def training_leg(nerf, K, pose, device, n_rays: int = 4096, steps: int = 4):
     target = torch.rand(n_rays, 3, device=device, generator=g)
     labels = torch.randint(0, INS_NUM, (n_rays,), device=device, generator=g)
     z = dm.z_val_sample(n_rays, targs.near, targs.far, targs.N_samples)
-    result = {"rays_per_step": n_rays, "losses": "mse + ins_criterion + ins_penalizer (coarse and fine), Adam 5e-4",
+    result = {"rays_per_step": n_rays, "losses": "mse + ins_criterion + ins_penalizer (coarse and fine), Adam 5e-4; the "
+              "Hungarian step of ins_criterion runs as a kernel (assign='device': scipy's algorithm in fp64, bit-identical "
+              "matching, tests/test_gpu_parity.py) so that the step never waits for the device",
               "backward": "HIP: backward-data + weight-gradient kernels (bf16x3), compositing backward"}
     coarse.train(); fine.train()
     for prec in ("fp32", "bf16x3"):
@@ -106,7 +108,7 @@ def training_leg(nerf, K, pose, device, n_rays: int = 4096, steps: int = 4):
         # losses are read back on the last timed step only (the reference reads them every i_print steps, train_dmsr.py:75)
         run = lambda i, report=False: trainer.train_step(
             i, rays, target, (pos, view, coarse, fine, targs), z, opt,
-            ins_loss=trainer.instance_loss(labels, INS_NUM),
+            ins_loss=trainer.instance_loss(labels, INS_NUM, assign="device"),
             penalizer=lambda raw, zz, depth: dm.ins_penalizer(raw, zz, depth, rays[1], targs), report=report)
         run(0)
         torch.cuda.synchronize()

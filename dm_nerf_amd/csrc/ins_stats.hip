@@ -225,6 +225,101 @@ __global__ __launch_bounds__(256) void ins_cost_kernel(const double* partial, in
   }
 }
 
+// The assignment itself on the device (opt-in: removes the training step's only wait for the device): rectangular linear
+// sum assignment of the V x K matrix cost_ce + cost_siou (V <= K), the shortest-augmenting-path algorithm scipy's
+// linear_sum_assignment runs (Crouse 2016), in fp64 like scipy, with scipy's scan order reproduced in the one place where
+// it decides between equal candidates (its `remaining` array: columns in reverse order, a removed entry replaced by the
+// last one; among equally short paths the LAST unassigned column in that order wins, else the FIRST column).
+// One wave; lane l owns columns l and l + 64.  match = {col_of [Vmax], class_of [K]}, -1 where unmatched.
+__global__ __launch_bounds__(64) void ins_assign_kernel(const float* host_blob, int* meta, int K, int Vmax, int* match) {
+  __shared__ double u[kMaxCols], v[kMaxCols], spc[kMaxCols];
+  __shared__ int path[kMaxCols], col4row[kMaxCols], row4col[kMaxCols], remaining[kMaxCols], pos[kMaxCols];
+  __shared__ unsigned char sr[kMaxCols], sc[kMaxCols];
+  const int lane = threadIdx.x;
+  const int V = meta[0];
+  const float* cost = host_blob + 2;
+  const double inf = __builtin_huge_val();
+  for (int j = lane; j < kMaxCols; j += 64) {
+    u[j] = 0.0; v[j] = 0.0;
+    col4row[j] = -1; row4col[j] = -1;
+  }
+  __syncthreads();
+  bool failed = meta[1] != 0 || V <= 0 || V > K;
+  for (int cur = 0; cur < V && !failed; ++cur) {
+    for (int j = lane; j < kMaxCols; j += 64) {
+      sr[j] = 0; sc[j] = 0; spc[j] = inf;
+      if (j < K) { remaining[j] = K - 1 - j; pos[j] = K - 1 - j; }
+    }
+    __syncthreads();
+    int num_remaining = K, sink = -1, i = cur;
+    double min_val = 0.0;
+    while (sink < 0) {
+      if (lane == 0) sr[i] = 1;
+      // relax the paths through row i; then the shortest over the remaining columns with scipy's choice among equals
+      double best = inf;
+      for (int j = lane; j < K; j += 64)
+        if (!sc[j]) {
+          const double r = min_val + (double)cost[(long)i * K + j] - u[i] - v[j];
+          if (r < spc[j]) { path[j] = i; spc[j] = r; }
+          best = spc[j] < best ? spc[j] : best;
+        }
+      for (int d = 32; d >= 1; d >>= 1) {
+        const double o = __shfl_xor(best, d);
+        best = o < best ? o : best;
+      }
+      if (!(best < inf)) { failed = true; break; }
+      int last_free = -1, first_any = 1 << 30;          // positions in `remaining` among the columns at `best`
+      for (int j = lane; j < K; j += 64)
+        if (!sc[j] && spc[j] == best) {
+          if (row4col[j] < 0) last_free = pos[j] > last_free ? pos[j] : last_free;
+          first_any = pos[j] < first_any ? pos[j] : first_any;
+        }
+      for (int d = 32; d >= 1; d >>= 1) {
+        const int a = __shfl_xor(last_free, d), b = __shfl_xor(first_any, d);
+        last_free = a > last_free ? a : last_free;
+        first_any = b < first_any ? b : first_any;
+      }
+      const int index = last_free >= 0 ? last_free : first_any;
+      const int j = remaining[index];
+      min_val = best;
+      if (row4col[j] < 0) sink = j; else i = row4col[j];
+      __syncthreads();
+      if (lane == 0) {
+        sc[j] = 1;
+        --num_remaining;
+        const int moved = remaining[num_remaining];
+        remaining[index] = moved;
+        pos[moved] = index;
+      }
+      num_remaining = __shfl(num_remaining, 0);
+      __syncthreads();
+    }
+    if (failed) break;
+    // dual variables (scipy's order of operations), then the augmentation along the path
+    for (int r = lane; r < V; r += 64)
+      if (r == cur) u[r] += min_val;
+      else if (sr[r]) u[r] += min_val - spc[col4row[r]];
+    for (int j = lane; j < K; j += 64)
+      if (sc[j]) v[j] -= min_val - spc[j];
+    __syncthreads();
+    if (lane == 0) {
+      int j = sink;
+      while (true) {
+        const int r = path[j];
+        row4col[j] = r;
+        const int t = col4row[r];
+        col4row[r] = j;
+        j = t;
+        if (r == cur) break;
+      }
+    }
+    __syncthreads();
+  }
+  if (lane == 0 && failed) meta[1] = 1;
+  for (int r = lane; r < Vmax; r += 64) match[r] = (!failed && r < V) ? col4row[r] : -1;
+  for (int j = lane; j < K; j += 64) match[Vmax + j] = failed ? -1 : row4col[j];
+}
+
 // loss terms for a matching: col_of[v] = column matched to class v (v < V), class_of[k] = class matched to column k or -1
 // out = {valid_ce + invalid_ce + valid_siou, valid_ce, invalid_ce, valid_siou} (evaluator.py:27-37)
 __global__ __launch_bounds__(64) void ins_loss_kernel(const float* cost, const float* colsum, const int* col_of,
@@ -232,11 +327,18 @@ __global__ __launch_bounds__(64) void ins_loss_kernel(const float* cost, const f
                                                       int K, int Vmax, float* out) {
   const int V = meta[0];
   const int lane = threadIdx.x;
+  if (meta[1] != 0 || V <= 0 || V > Vmax) {          // no assignment (device-side matching on labels the kernels do not take)
+    if (lane < 4) out[lane] = __builtin_nanf("");
+    return;
+  }
   float ce = 0.f, siou = 0.f, inv = 0.f;
   int unmatched = 0;
   for (int v = lane; v < V; v += 64) {
-    ce += cost[v * K + col_of[v]];
-    siou += cost[(long)Vmax * K + v * K + col_of[v]];
+    const int c = col_of[v];
+    if (c >= 0) {
+      ce += cost[v * K + c];
+      siou += cost[(long)Vmax * K + v * K + c];
+    }
   }
   for (int k = lane; k < K; k += 64)
     if (class_of[k] < 0) {
@@ -268,6 +370,10 @@ __global__ __launch_bounds__(256) void ins_loss_bwd_kernel(const float* stats, c
                                                            float* g_stats) {
   __shared__ int n_unmatched;
   const int V = meta[0];
+  if (meta[1] != 0 || V <= 0 || V > Vmax) {
+    for (int e = threadIdx.x; e < 3 * Vmax * K; e += 256) g_stats[e] = 0.f;
+    return;
+  }
   if (threadIdx.x == 0) {
     int u = 0;
     for (int k = 0; k < K; ++k) u += class_of[k] < 0;
@@ -359,6 +465,14 @@ extern "C" int dmn_ins_cost(const double* partial, float* stats, const float* co
   if (!stats || !count || !meta || !cost || !colsum || !host_blob) return DMN_ERR_BAD_ARG;
   hipLaunchKernelGGL(ins_cost_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, dmn_ins_stats_chunks(n_rays),
                      stats, count, meta, n_rays, n_rays_dev, n_cols, max_classes, cost, colsum, host_blob);
+  return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
+}
+
+extern "C" int dmn_ins_assign(const float* host_blob, int* meta, int n_cols, int max_classes, int* match, void* stream) {
+  if (n_cols <= 0 || n_cols > kMaxCols || max_classes <= 0 || max_classes > kMaxCols) return DMN_ERR_BAD_ARG;
+  if (!host_blob || !meta || !match) return DMN_ERR_BAD_ARG;
+  hipLaunchKernelGGL(ins_assign_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, host_blob, meta, n_cols, max_classes,
+                     match);
   return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
 }
 

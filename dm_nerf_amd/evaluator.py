@@ -70,7 +70,7 @@ class _InsCriterionFn(torch.autograd.Function):
     columns): the caller falls back to the tensor-operation path."""
 
     @staticmethod
-    def forward(ctx, labels, ins_num, reduce, *preds):
+    def forward(ctx, labels, ins_num, reduce, assign, *preds):
         from scipy.optimize import linear_sum_assignment
         lib = load()
         preds = [ops._dev(p, "pred_ins").contiguous() for p in preds]
@@ -104,16 +104,21 @@ class _InsCriterionFn(torch.autograd.Function):
         for i in range(m):
             check(lib.dmn_ins_cost(None if reduce is not None else ptr(partial[i]), ptr(stats[i]), ptr(count), ptr(meta), n,
                                    ptr(n_dev), k, ins_num, ptr(cost[i]), ptr(colsum[i]), ptr(blob[i]), st), "dmn_ins_cost")
-        host = blob.cpu().numpy()                                                     # the one wait for the device
-        v = int(host[0, 0])
-        if host[0, 1] != 0.0 or v == 0:
-            return (None,) * (4 * m)
-        match = np.full((m, ins_num + k), -1, dtype=np.int32)
-        for i in range(m):
-            rows, cols = linear_sum_assignment(host[i, 2:].reshape(ins_num, k)[:v])    # reorder(), :42-52
-            match[i, rows] = cols                                                     # col_of [ins_num]
-            match[i, ins_num + cols] = rows                                           # class_of [k]
-        match_t = torch.from_numpy(match).to(dev)
+        if assign == "device":          # the same assignment without the wait (csrc/ins_stats.hip: ins_assign_kernel)
+            match_t = torch.empty(m, ins_num + k, dtype=torch.int32, device=dev)
+            for i in range(m):
+                check(lib.dmn_ins_assign(ptr(blob[i]), ptr(meta), k, ins_num, ptr(match_t[i]), st), "dmn_ins_assign")
+        else:
+            host = blob.cpu().numpy()                                                 # the one wait for the device
+            v = int(host[0, 0])
+            if host[0, 1] != 0.0 or v == 0:
+                return (None,) * (4 * m)
+            match = np.full((m, ins_num + k), -1, dtype=np.int32)
+            for i in range(m):
+                rows, cols = linear_sum_assignment(host[i, 2:].reshape(ins_num, k)[:v])    # reorder(), :42-52
+                match[i, rows] = cols                                                 # col_of [ins_num]
+                match[i, ins_num + cols] = rows                                       # class_of [k]
+            match_t = torch.from_numpy(match).to(dev)
         out = torch.empty(m, 4, dtype=torch.float32, device=dev)
         for i in range(m):
             check(lib.dmn_ins_loss(ptr(cost[i]), ptr(colsum[i]), ptr(match_t[i]), ptr(match_t[i]) + 4 * ins_num, ptr(meta),
@@ -143,10 +148,10 @@ class _InsCriterionFn(torch.autograd.Function):
             check(lib.dmn_ins_stats_bwd(ptr(pred), ptr(classes), n, k, ctx.ins_num, ptr(g_stats), ptr(g_pred), st),
                   "dmn_ins_stats_bwd")
             g_preds.append(g_pred)
-        return (None, None, None, *g_preds)
+        return (None, None, None, None, *g_preds)
 
 
-def ins_criterion_many(preds, gt_labels: torch.Tensor, ins_num: int, reduce=None):
+def ins_criterion_many(preds, gt_labels: torch.Tensor, ins_num: int, reduce=None, assign: str = "host"):
     """``ins_criterion`` for several predictions with the same labels (``[ins_coarse, ins_fine]`` of a training step,
     train_dmsr.py:38-45) behind ONE wait for the device instead of one per prediction: a list of the 4-tuples
     ``ins_criterion`` returns.  Falls back to separate calls where the fused kernels do not apply."""
@@ -155,13 +160,14 @@ def ins_criterion_many(preds, gt_labels: torch.Tensor, ins_num: int, reduce=None
     ok = (len(preds) > 0 and all(p.dim() == 2 and p.shape == preds[0].shape and p.is_cuda for p in preds)
           and preds[0].shape[1] == ins_num and 0 < preds[0].shape[0] == labels.shape[0] and ins_num <= 128)
     if ok:
-        got = _InsCriterionFn.apply(labels.to(preds[0].device).contiguous(), ins_num, reduce, *preds)
+        got = _InsCriterionFn.apply(labels.to(preds[0].device).contiguous(), ins_num, reduce, assign, *preds)
         if got[0] is not None:
             return [tuple(got[4 * i: 4 * i + 4]) for i in range(len(preds))]
     return [ins_criterion(p, gt_labels, ins_num, reduce=reduce) for p in preds]
 
 
-def ins_criterion(pred_ins: torch.Tensor, gt_labels: torch.Tensor, ins_num: int, reduce=None, fused: bool = True):
+def ins_criterion(pred_ins: torch.Tensor, gt_labels: torch.Tensor, ins_num: int, reduce=None, fused: bool = True,
+                  assign: str = "host"):
     """``(ins_loss_sum, valid_ce, invalid_ce, valid_siou)`` of networks/evaluator.py:19-38 for ``pred_ins [N, ins_num]``
     (the rendered, sigmoided instance map) and integer ``gt_labels [N]``.  All four are 0-dim tensors
     (the reference's ``invalid_ce`` is ``tensor([0])`` when every column is matched).
@@ -171,6 +177,11 @@ def ins_criterion(pred_ins: torch.Tensor, gt_labels: torch.Tensor, ins_num: int,
     Matching and normalisation then see the whole batch (evaluator.py:21,60-70), every rank computes the same loss
     value, and its backward reaches the rank's own rays only -- so gradients must be SUMMED over ranks.
 
+    ``assign``: "host" runs the Hungarian step with scipy on the host as the reference does (one wait for the device per
+    call); "device" runs the same algorithm (scipy's shortest augmenting paths, fp64, its choice among equal candidates) in
+    a kernel, so that the call never waits -- labels outside [0, 1024) or more labels than columns then give NaN losses
+    instead of the fallback / the error of the host form.
+
     The loss head runs as fused kernels (``csrc/ins_stats.hip``: label classes, class statistics, cost matrices, loss
     terms and their gradient; under ``reduce`` with the three all-reduces in between), with the Hungarian step on the host;
     ``fused=False`` is the same arithmetic in tensor operations."""
@@ -178,12 +189,14 @@ def ins_criterion(pred_ins: torch.Tensor, gt_labels: torch.Tensor, ins_num: int,
 
     if pred_ins.dim() != 2 or pred_ins.shape[1] != ins_num or gt_labels.shape[0] != pred_ins.shape[0]:
         raise ValueError("pred_ins must be [N, ins_num] and gt_labels [N]")
+    if assign not in ("host", "device"):
+        raise ValueError("assign is 'host' or 'device'")
     n = pred_ins.shape[0]
     labels = gt_labels if gt_labels.dtype == torch.int64 else gt_labels.long()
     if fused and n > 0 and ins_num <= 128 and pred_ins.is_cuda:
         # five launches instead of ~100 tensor operations (the host is the bottleneck of this part of a training step);
         # ``fused=False`` is the same arithmetic written with tensor operations
-        got = _InsCriterionFn.apply(labels.to(pred_ins.device).contiguous(), ins_num, reduce, pred_ins)
+        got = _InsCriterionFn.apply(labels.to(pred_ins.device).contiguous(), ins_num, reduce, assign, pred_ins)
         if got[0] is not None:
             return got
     if reduce is None:

@@ -36,15 +36,16 @@ class _MseFn(torch.autograd.Function):
         return diff * (g * (2.0 / diff.numel())), None
 
 
-def instance_loss(gt_labels, ins_num: int, reduce=None) -> Callable:
+def instance_loss(gt_labels, ins_num: int, reduce=None, assign: str = "host") -> Callable:
     """The ``ins_loss`` callable of ``train_step`` for ``dm_nerf_amd.ins_criterion`` on fixed labels: ``f(pred)`` is the loss
-    sum of one map, ``f.many([coarse, fine])`` evaluates both behind one wait for the device."""
+    sum of one map, ``f.many([coarse, fine])`` evaluates both behind one wait for the device -- or, with
+    ``assign="device"`` (the Hungarian step in a kernel, ``ins_criterion``), behind none."""
     from .evaluator import ins_criterion, ins_criterion_many
 
     def one(pred):
-        return ins_criterion(pred, gt_labels, ins_num, reduce=reduce)[0]
+        return ins_criterion(pred, gt_labels, ins_num, reduce=reduce, assign=assign)[0]
 
-    one.many = lambda preds: [t[0] for t in ins_criterion_many(preds, gt_labels, ins_num, reduce=reduce)]
+    one.many = lambda preds: [t[0] for t in ins_criterion_many(preds, gt_labels, ins_num, reduce=reduce, assign=assign)]
     return one
 
 

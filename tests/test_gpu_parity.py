@@ -1029,6 +1029,34 @@ def test_fused_loss_head_equals_the_tensor_operation_form():
     assert [float(x) for x in a] == [float(x) for x in b]
 
 
+def test_device_side_assignment_is_scipys_assignment():
+    """``assign="device"``: the Hungarian step as a kernel (scipy's shortest-augmenting-path algorithm in fp64) gives the
+    loss terms and gradients of the host form bit for bit -- every G11 case, training-size batches, and predictions with
+    duplicated and constant columns, where the choice among equally good columns is scipy's scan order."""
+    sets = [cases.criterion_case(n, k, present, seed) + (k,) for n, k, present, seed in cases.CRITERION_CASES.values()]
+    rng = np.random.default_rng(77)
+    for n, k, present in ((4096, 13, (0, 1, 2, 5, 7, 11, 12)), (3000, 93, tuple(range(0, 93, 2))), (777, 40, tuple(range(40)))):
+        sets.append((rng.uniform(0.01, 0.99, size=(n, k)).astype(np.float32),
+                     rng.choice(np.asarray(present), size=n).astype(np.int64), k))
+    pred, labels, k = sets[0]
+    dup = pred.copy(); dup[:, 1] = dup[:, 0]; dup[:, 5] = dup[:, 0]; dup[:, 9] = dup[:, 8]      # equal cost columns
+    sets.append((dup, labels, k))
+    sets.append((np.full_like(pred, 0.5), labels, k))                                          # a constant cost matrix
+    for pred, labels, k in sets:
+        lab = torch.from_numpy(labels).to(DEV)
+        got = []
+        for assign in ("host", "device"):
+            p = G(pred).requires_grad_(True)
+            out = dm.ins_criterion(p, lab, k, assign=assign)
+            (out[0] + 0.5 * out[3]).backward()
+            got.append(([float(o.detach()) for o in out], p.grad.clone()))
+        assert got[0][0] == got[1][0], (got[0][0], got[1][0])
+        assert torch.equal(got[0][1], got[1][1])
+    # labels the kernels do not take: NaN instead of the host form's fallback
+    bad = dm.ins_criterion(G(sets[0][0]), torch.from_numpy(sets[0][1]).to(DEV) * 1000, sets[0][2], assign="device")
+    assert all(np.isnan(float(t)) for t in bad)
+
+
 # ---- ray-sharded training is batch-exact (SURVEY.md section 8e) ----------------------------------------------
 class _TwoShardReducer:
     """Single-process stand-in for parallel.ShardReducer: pass 1 records what a shard would contribute, pass 2 returns

@@ -29,6 +29,8 @@ ap.add_argument("--rays", type=int, default=4096, help="rays per optimisation st
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "fp16x3"])
 ap.add_argument("--instance", action="store_true", help="add the instance-matching loss on random labels")
+ap.add_argument("--assign", default="device", choices=["host", "device"],
+                help="Hungarian step of the instance loss: scipy on the host (one wait for the device per step) or the kernel")
 ap.add_argument("--separate-ins", action="store_true", help="evaluate the two instance maps in two calls (two waits for the device)")
 ap.add_argument("--penalize", action="store_true", help="add the emptiness penalizer (configs: tolerance = deta_w = 0.05)")
 ns = ap.parse_args()
@@ -66,7 +68,7 @@ opt = trainer.make_optimizer(coarse, fine)
 args.tolerance, args.deta_w = 0.05, 0.05
 reducer = parallel.ShardReducer() if world > 1 else None
 bucket = parallel.GradBucket([coarse, fine])                # the weight-gradient kernels write straight into it
-ins = trainer.instance_loss(labels, 13, reduce=reducer) if ns.instance else None
+ins = trainer.instance_loss(labels, 13, reduce=reducer, assign=ns.assign) if ns.instance else None
 if ins is not None and ns.separate_ins and hasattr(ins, "many"):
     del ins.many
 pen = (lambda raw, zz, depth: dm.ins_penalizer(raw, zz, depth, rays[1], args, reduce=reducer)) if ns.penalize else None

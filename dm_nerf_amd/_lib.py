@@ -81,7 +81,7 @@ SIGNATURES = {
     "dmn_ins_stats_chunks": (c_int, [c_long]),
     "dmn_ins_stats_scan": (c_int, [_P, _P, c_long, c_int, c_int, _P, _P]),
     "dmn_ins_cost": (c_int, [_P, _P, _P, _P, c_long, _P, c_int, c_int, _P, _P, _P, _P]),
-    "dmn_ins_assign": (c_int, [_P, _P, c_int, c_int, _P, _P]),
+    "dmn_ins_assign": (c_int, [_P, _P, c_int, c_int, _P, c_int, _P]),
     "dmn_ins_loss": (c_int, [_P, _P, _P, _P, _P, c_long, _P, c_int, c_int, _P, _P]),
     "dmn_ins_loss_bwd": (c_int, [_P, _P, _P, _P, _P, c_long, _P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "dmn_composite_fwd": (c_int, [_P, _P, c_long, _P, c_long, c_int, c_int, c_int, _P, _P, _P, _P, _P]),

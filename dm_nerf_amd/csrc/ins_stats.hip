@@ -231,93 +231,157 @@ __global__ __launch_bounds__(256) void ins_cost_kernel(const double* partial, in
 // it decides between equal candidates (its `remaining` array: columns in reverse order, a removed entry replaced by the
 // last one; among equally short paths the LAST unassigned column in that order wins, else the FIRST column).
 // One wave; lane l owns columns l and l + 64.  match = {col_of [Vmax], class_of [K]}, -1 where unmatched.
-__global__ __launch_bounds__(64) void ins_assign_kernel(const float* host_blob, int* meta, int K, int Vmax, int* match) {
-  __shared__ double u[kMaxCols], v[kMaxCols], spc[kMaxCols];
-  __shared__ int path[kMaxCols], col4row[kMaxCols], row4col[kMaxCols], remaining[kMaxCols], pos[kMaxCols];
-  __shared__ unsigned char sr[kMaxCols], sc[kMaxCols];
+// wave-wide min / max, result in every lane: DPP inside the 16-lane rows, then the four row results by v_readlane
+// (ds_bpermute-based shuffles cost ~100 cycles each in a dependent chain: 129 us per call of the kernel below with them)
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const unsigned lo = (unsigned)dpp_i<CTRL>((int)(unsigned)b), hi = (unsigned)dpp_i<CTRL>((int)(unsigned)(b >> 32));
+  return __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double lane_d(double v, int l) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+  return __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave_min_d(double v) {
+  double t;
+  t = dpp_d<0xB1>(v); v = t < v ? t : v;
+  t = dpp_d<0x4E>(v); v = t < v ? t : v;
+  t = dpp_d<0x124>(v); v = t < v ? t : v;
+  t = dpp_d<0x128>(v); v = t < v ? t : v;
+  const double a = lane_d(v, 0), b = lane_d(v, 16), c = lane_d(v, 32), d = lane_d(v, 48);
+  const double ab = b < a ? b : a, cd = d < c ? d : c;
+  return cd < ab ? cd : ab;
+}
+template <bool MAX>
+__device__ __forceinline__ int wave_ext_i(int v) {
+  int t;
+  t = dpp_i<0xB1>(v); v = MAX ? (t > v ? t : v) : (t < v ? t : v);
+  t = dpp_i<0x4E>(v); v = MAX ? (t > v ? t : v) : (t < v ? t : v);
+  t = dpp_i<0x124>(v); v = MAX ? (t > v ? t : v) : (t < v ? t : v);
+  t = dpp_i<0x128>(v); v = MAX ? (t > v ? t : v) : (t < v ? t : v);
+  const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16),
+            c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+  const int ab = MAX ? (a > b ? a : b) : (a < b ? a : b), cd = MAX ? (c > d ? c : d) : (c < d ? c : d);
+  return MAX ? (ab > cd ? ab : cd) : (ab < cd ? ab : cd);
+}
+
+__device__ __forceinline__ int sel_i(int a0, int a1, int j) {      // element j of a [128] array held as two registers per lane
+  const int l = __builtin_amdgcn_readfirstlane(j & 63);
+  return j < 64 ? __builtin_amdgcn_readlane(a0, l) : __builtin_amdgcn_readlane(a1, l);
+}
+__device__ __forceinline__ double sel_d(double a0, double a1, int j) {
+  const int l = __builtin_amdgcn_readfirstlane(j & 63);
+  return j < 64 ? lane_d(a0, l) : lane_d(a1, l);
+}
+__device__ __forceinline__ int first_col(bool hit0, bool hit1) {    // lowest column index with a hit (-1: none)
+  const unsigned long long m0 = __ballot(hit0), m1 = __ballot(hit1);
+  return m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : -1);
+}
+
+// State in registers: lane l owns columns l, l + 64 (v, shortest path costs, path, row4col, position in scipy's `remaining`
+// order, visited flag) and rows l, l + 64 (u, col4row, visited flag); the chosen column / row is read from its owner by
+// v_readlane.  LDS holds the cost matrix and, once per row, the path costs for the dual update.
+__global__ __launch_bounds__(64) void ins_assign_kernel(const float* host_blob, int* meta, int K, int Vmax, int* match,
+                                                        int cost_in_lds) {
+  extern __shared__ float cmat[];                        // the V x K cost matrix (cost_in_lds; else read from global memory)
+  __shared__ double spc_lds[kMaxCols];
   const int lane = threadIdx.x;
   const int V = meta[0];
-  const float* cost = host_blob + 2;
-  const double inf = __builtin_huge_val();
-  for (int j = lane; j < kMaxCols; j += 64) {
-    u[j] = 0.0; v[j] = 0.0;
-    col4row[j] = -1; row4col[j] = -1;
-  }
-  __syncthreads();
-  bool failed = meta[1] != 0 || V <= 0 || V > K;
-  for (int cur = 0; cur < V && !failed; ++cur) {
-    for (int j = lane; j < kMaxCols; j += 64) {
-      sr[j] = 0; sc[j] = 0; spc[j] = inf;
-      if (j < K) { remaining[j] = K - 1 - j; pos[j] = K - 1 - j; }
-    }
+  host_blob += (long)blockIdx.x * (2 + (long)Vmax * K);  // one workgroup per problem (the maps of a step share labels and meta)
+  match += (long)blockIdx.x * (Vmax + K);
+  const float* const gcost = host_blob + 2;
+  if (cost_in_lds) {
+    const int n = (V < Vmax ? (V > 0 ? V : 0) : Vmax) * K;
+    for (int e = lane; e < n; e += 64) cmat[e] = gcost[e];
     __syncthreads();
+  }
+  auto cost_at = [&](int e) { return cost_in_lds ? cmat[e] : gcost[e]; };     // an LDS read, not a flat one
+  const double inf = __builtin_huge_val();
+  const int c0 = lane, c1 = lane + 64;                   // this lane's columns (and rows)
+  const bool has0 = c0 < K, has1 = c1 < K;
+  double u0 = 0.0, u1 = 0.0, v0 = 0.0, v1 = 0.0;
+  int col4row0 = -1, col4row1 = -1, row4col0 = -1, row4col1 = -1;
+  bool failed = meta[1] != 0 || V <= 0 || V > K || V > Vmax;
+  for (int cur = 0; cur < V && !failed; ++cur) {
+    double spc0 = inf, spc1 = inf;
+    int path0 = -1, path1 = -1;
+    int pos0 = K - 1 - c0, pos1 = K - 1 - c1;            // scipy fills `remaining` in reverse column order
+    bool sc0 = false, sc1 = false, sr0 = false, sr1 = false;
     int num_remaining = K, sink = -1, i = cur;
     double min_val = 0.0;
     while (sink < 0) {
-      if (lane == 0) sr[i] = 1;
+      if (i == c0) sr0 = true;
+      if (i == c1) sr1 = true;
+      const double ui = sel_d(u0, u1, i);
       // relax the paths through row i; then the shortest over the remaining columns with scipy's choice among equals
-      double best = inf;
-      for (int j = lane; j < K; j += 64)
-        if (!sc[j]) {
-          const double r = min_val + (double)cost[(long)i * K + j] - u[i] - v[j];
-          if (r < spc[j]) { path[j] = i; spc[j] = r; }
-          best = spc[j] < best ? spc[j] : best;
-        }
-      for (int d = 32; d >= 1; d >>= 1) {
-        const double o = __shfl_xor(best, d);
-        best = o < best ? o : best;
+      if (has0 && !sc0) {
+        const double r = min_val + (double)cost_at(i * K + c0) - ui - v0;
+        if (r < spc0) { path0 = i; spc0 = r; }
       }
+      if (has1 && !sc1) {
+        const double r = min_val + (double)cost_at(i * K + c1) - ui - v1;
+        if (r < spc1) { path1 = i; spc1 = r; }
+      }
+      const bool live0 = has0 && !sc0, live1 = has1 && !sc1;
+      double best = live0 ? spc0 : inf;
+      best = live1 && spc1 < best ? spc1 : best;
+      best = wave_min_d(best);
       if (!(best < inf)) { failed = true; break; }
-      int last_free = -1, first_any = 1 << 30;          // positions in `remaining` among the columns at `best`
-      for (int j = lane; j < K; j += 64)
-        if (!sc[j] && spc[j] == best) {
-          if (row4col[j] < 0) last_free = pos[j] > last_free ? pos[j] : last_free;
-          first_any = pos[j] < first_any ? pos[j] : first_any;
-        }
-      for (int d = 32; d >= 1; d >>= 1) {
-        const int a = __shfl_xor(last_free, d), b = __shfl_xor(first_any, d);
-        last_free = a > last_free ? a : last_free;
-        first_any = b < first_any ? b : first_any;
+      const bool tie0 = live0 && spc0 == best, tie1 = live1 && spc1 == best;
+      int last_free = -1, first_any = 1 << 30;           // positions in `remaining` among the columns at `best`
+      if (tie0) { if (row4col0 < 0) last_free = pos0; first_any = pos0; }
+      if (tie1) {
+        if (row4col1 < 0) last_free = pos1 > last_free ? pos1 : last_free;
+        first_any = pos1 < first_any ? pos1 : first_any;
       }
+      last_free = wave_ext_i<true>(last_free);
+      first_any = wave_ext_i<false>(first_any);
       const int index = last_free >= 0 ? last_free : first_any;
-      const int j = remaining[index];
+      const int j = first_col(live0 && pos0 == index, live1 && pos1 == index);      // remaining[index]
       min_val = best;
-      if (row4col[j] < 0) sink = j; else i = row4col[j];
-      __syncthreads();
-      if (lane == 0) {
-        sc[j] = 1;
-        --num_remaining;
-        const int moved = remaining[num_remaining];
-        remaining[index] = moved;
-        pos[moved] = index;
-      }
-      num_remaining = __shfl(num_remaining, 0);
-      __syncthreads();
+      const int rj = sel_i(row4col0, row4col1, j);
+      if (rj < 0) sink = j; else i = rj;
+      // remaining[index] = remaining[--num_remaining]; column j leaves
+      --num_remaining;
+      const int moved = first_col(live0 && pos0 == num_remaining, live1 && pos1 == num_remaining);
+      if (moved == c0) pos0 = index;
+      if (moved == c1) pos1 = index;
+      if (j == c0) sc0 = true;
+      if (j == c1) sc1 = true;
     }
     if (failed) break;
-    // dual variables (scipy's order of operations), then the augmentation along the path
-    for (int r = lane; r < V; r += 64)
-      if (r == cur) u[r] += min_val;
-      else if (sr[r]) u[r] += min_val - spc[col4row[r]];
-    for (int j = lane; j < K; j += 64)
-      if (sc[j]) v[j] -= min_val - spc[j];
+    // dual variables (scipy's order of operations); the path costs go through LDS for the per-row gather
     __syncthreads();
-    if (lane == 0) {
-      int j = sink;
-      while (true) {
-        const int r = path[j];
-        row4col[j] = r;
-        const int t = col4row[r];
-        col4row[r] = j;
-        j = t;
-        if (r == cur) break;
-      }
+    if (has0) spc_lds[c0] = spc0;
+    if (has1) spc_lds[c1] = spc1;
+    __syncthreads();
+    if (c0 == cur) u0 += min_val; else if (sr0 && c0 < V) u0 += min_val - spc_lds[col4row0];
+    if (c1 == cur) u1 += min_val; else if (sr1 && c1 < V) u1 += min_val - spc_lds[col4row1];
+    if (sc0) v0 -= min_val - spc0;
+    if (sc1) v1 -= min_val - spc1;
+    // augmentation along the path
+    int j = sink;
+    while (true) {
+      const int r = sel_i(path0, path1, j);
+      if (j == c0) row4col0 = r;
+      if (j == c1) row4col1 = r;
+      const int t = sel_i(col4row0, col4row1, r);
+      if (r == c0) col4row0 = j;
+      if (r == c1) col4row1 = j;
+      j = t;
+      if (r == cur) break;
     }
-    __syncthreads();
   }
   if (lane == 0 && failed) meta[1] = 1;
-  for (int r = lane; r < Vmax; r += 64) match[r] = (!failed && r < V) ? col4row[r] : -1;
-  for (int j = lane; j < K; j += 64) match[Vmax + j] = failed ? -1 : row4col[j];
+  if (c0 < Vmax) match[c0] = (!failed && c0 < V) ? col4row0 : -1;
+  if (c1 < Vmax) match[c1] = (!failed && c1 < V) ? col4row1 : -1;
+  if (has0) match[Vmax + c0] = failed ? -1 : row4col0;
+  if (has1) match[Vmax + c1] = failed ? -1 : row4col1;
 }
 
 // loss terms for a matching: col_of[v] = column matched to class v (v < V), class_of[k] = class matched to column k or -1
@@ -468,11 +532,14 @@ extern "C" int dmn_ins_cost(const double* partial, float* stats, const float* co
   return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
 }
 
-extern "C" int dmn_ins_assign(const float* host_blob, int* meta, int n_cols, int max_classes, int* match, void* stream) {
-  if (n_cols <= 0 || n_cols > kMaxCols || max_classes <= 0 || max_classes > kMaxCols) return DMN_ERR_BAD_ARG;
+extern "C" int dmn_ins_assign(const float* host_blob, int* meta, int n_cols, int max_classes, int* match, int problems,
+                              void* stream) {
+  if (n_cols <= 0 || n_cols > kMaxCols || max_classes <= 0 || max_classes > kMaxCols || problems <= 0) return DMN_ERR_BAD_ARG;
   if (!host_blob || !meta || !match) return DMN_ERR_BAD_ARG;
-  hipLaunchKernelGGL(ins_assign_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, host_blob, meta, n_cols, max_classes,
-                     match);
+  const size_t bytes = (size_t)max_classes * n_cols * sizeof(float);
+  const int in_lds = bytes <= 48 * 1024;               // 110 x 110; beyond that the matrix stays in global memory
+  hipLaunchKernelGGL(ins_assign_kernel, dim3(problems), dim3(64), in_lds ? bytes : 0, (hipStream_t)stream, host_blob, meta,
+                     n_cols, max_classes, match, in_lds);
   return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
 }
 

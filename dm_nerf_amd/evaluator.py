@@ -106,8 +106,7 @@ class _InsCriterionFn(torch.autograd.Function):
                                    ptr(n_dev), k, ins_num, ptr(cost[i]), ptr(colsum[i]), ptr(blob[i]), st), "dmn_ins_cost")
         if assign == "device":          # the same assignment without the wait (csrc/ins_stats.hip: ins_assign_kernel)
             match_t = torch.empty(m, ins_num + k, dtype=torch.int32, device=dev)
-            for i in range(m):
-                check(lib.dmn_ins_assign(ptr(blob[i]), ptr(meta), k, ins_num, ptr(match_t[i]), st), "dmn_ins_assign")
+            check(lib.dmn_ins_assign(ptr(blob), ptr(meta), k, ins_num, ptr(match_t), m, st), "dmn_ins_assign")
         else:
             host = blob.cpu().numpy()                                                 # the one wait for the device
             v = int(host[0, 0])

@@ -251,7 +251,8 @@ int dmn_ins_cost(const double* partial, float* stats, const float* count, const 
 /* The assignment on the device instead of scipy on the host (same algorithm, fp64, scipy's choice among equal
  * candidates): host_blob as dmn_ins_cost wrote it -> match = {col_of [max_classes], class_of [n_cols]}; sets meta[1] where
  * no assignment exists (the loss terms are then computed on -1 entries: the caller checks meta when it next may wait). */
-int dmn_ins_assign(const float* host_blob, int* meta, int n_cols, int max_classes, int* match, void* stream);
+int dmn_ins_assign(const float* host_blob, int* meta, int n_cols, int max_classes, int* match, int problems,
+                   void* stream);      /* `problems` blobs / match arrays back to back, one workgroup each */
 int dmn_ins_loss(const float* cost, const float* colsum, const int* col_of, const int* class_of, const int* meta,
                  long n_rays, const float* n_rays_dev, int n_cols, int max_classes, float* out4, void* stream);
 int dmn_ins_loss_bwd(const float* stats, const float* count, const float* colsum, const int* class_of, const int* meta,

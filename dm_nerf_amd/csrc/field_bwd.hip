@@ -677,6 +677,28 @@ extern "C" int dmn_field_bwd_data(const float* g_raw, const float* save, const f
   return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
 }
 
+namespace {
+// A second stream for the smallest weight-gradient GEMMs (25 KB of LDS, < 100 registers per wave): they fit into a CU
+// beside a workgroup of the ring kernel (128 KB of LDS, one wave per SIMD) and run in its shadow instead of behind it.
+// Fork / join by events; created once per device on first use.
+struct SideStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+SideStream* side_stream() {
+  static SideStream per_device[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  SideStream& s = per_device[dev];
+  if (s.stream == nullptr) {
+    if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) { s.stream = nullptr; return nullptr; }
+    if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+  }
+  return &s;
+}
+}  // namespace
+
 extern "C" long dmn_field_wgrad_workspace_floats(int ins_num, int splits) {
   if (ins_num < 0 || ins_tiles(ins_num) > kMaxInsTiles || splits <= 0) return DMN_ERR_BAD_ARG;
   const long small = wgrad_index_len(ins_tiles(ins_num)) - kWgradBigLen;
@@ -706,24 +728,37 @@ extern "C" int dmn_field_bwd_weights(const float* save, const float* grad_record
   a.splits = splits;
   wgemm_table(T, a.gemm);
   {
+#ifndef DMN_WG_SIDE
+#define DMN_WG_SIDE 1
+#endif
+    SideStream* side = x3 && DMN_WG_SIDE ? side_stream() : nullptr;
+    hipStream_t st2 = st;
+    if (side != nullptr && hipEventRecord(side->fork, st) == hipSuccess &&
+        hipStreamWaitEvent(side->stream, side->fork, 0) == hipSuccess)
+      st2 = side->stream;
+    // the smallest GEMMs first, on the side stream: they trickle into the CUs beside the ring kernel's workgroups
+    const int view[] = {12};
+    launch_class<4, 1, 4, 1>(a, view, 1, x3, st2);
+    const int rgbo[] = {15};
+    launch_class<1, 4, 1, 4>(a, rgbo, 1, x3, st2);
+    const int inso[] = {14};
+    switch (T) {
+      case 1: launch_class<1, 4, 1, 4>(a, inso, 1, x3, st2); break;
+      case 2: launch_class<2, 4, 2, 2>(a, inso, 1, x3, st2); break;
+      case 3: launch_class<3, 4, 1, 4>(a, inso, 1, x3, st2); break;
+      case 4: launch_class<4, 4, 2, 2>(a, inso, 1, x3, st2); break;
+    }
     const int big[] = {1, 2, 3, 4, 5, 7, 8, 9, 10};
     launch_class<8, 8, 2, 2>(a, big, 9, x3, st);
     const int pe[] = {0, 6};
     launch_class<8, 2, 4, 1>(a, pe, 2, x3, st);
     const int half[] = {11, 13};
     launch_class<4, 8, 2, 2>(a, half, 2, x3, st);
-    const int view[] = {12};
-    launch_class<4, 1, 4, 1>(a, view, 1, x3, st);
-    const int rgbo[] = {15};
-    launch_class<1, 4, 1, 4>(a, rgbo, 1, x3, st);
     const int dens[] = {16};
     launch_class<1, 8, 1, 4>(a, dens, 1, x3, st);
-    const int inso[] = {14};
-    switch (T) {
-      case 1: launch_class<1, 4, 1, 4>(a, inso, 1, x3, st); break;
-      case 2: launch_class<2, 4, 2, 2>(a, inso, 1, x3, st); break;
-      case 3: launch_class<3, 4, 1, 4>(a, inso, 1, x3, st); break;
-      case 4: launch_class<4, 4, 2, 2>(a, inso, 1, x3, st); break;
+    if (st2 != st) {                                     // join: the reduction reads every partial sum
+      if (hipEventRecord(side->join, st2) != hipSuccess || hipStreamWaitEvent(st, side->join, 0) != hipSuccess)
+        return DMN_ERR_LAUNCH;
     }
   }
   const long n = wgrad_index_len(T);

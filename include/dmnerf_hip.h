@@ -191,6 +191,10 @@ int dmn_field_wgrad_index(int ins_num, int32_t* index_out);
 int dmn_field_bwd_data(const float* g_raw, const float* save, const float* bwd_blob, long n_points, int ins_num,
                        float* grad_record, void* stream);
 long dmn_field_wgrad_workspace_floats(int ins_num, int splits);
+/* With DMN_PREC_BF16X3 the smallest GEMMs run on a second, library-owned stream beside the kernel of the nine 256x256
+ * GEMMs (forked from and joined to `stream` by events: everything the call launches is ordered after the work already
+ * on `stream` and before the work submitted to it afterwards); that stream and its two events are created once per
+ * device on first use -- the only objects this library ever creates. */
 int dmn_field_bwd_weights(const float* save, const float* grad_record, long n_points, int ins_num,
                           const int32_t* wgrad_index, int splits, int precision, float* workspace,
                           float* grads_flat, int accumulate, void* stream);

@@ -134,12 +134,25 @@ def training_leg(nerf, K, pose, device, n_rays: int = 4096, steps: int = 4):
                       "around dmn_field_bwd_weights, both networks)", "bound": "hbm", "achieved": wg_bytes / t_wg / 1e9,
             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": wg_bytes / t_wg / 1e9 / PEAK_HBM_GBS,
             "algorithmic_bytes_per_step": wg_bytes,
-            "traffic": 29.8e9 if INS_NUM == 13 and n_rays == 4096 else None,      # 29.1 GB fetched + 0.65 GB of partials written
-            "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per step, profiles/r02e_train_hbm_traffic.txt"}
+            "traffic": None}
+        meas = measured_traffic(f"train_rays{n_rays}_ins{INS_NUM}_wgrad")      # counter passes of exactly this step shape
+        if meas is not None:
+            entry["roofline_weight_gradients"]["traffic"] = meas["hbm_bytes_per_step"]
+            entry["roofline_weight_gradients"]["traffic_source"] = meas["source"]
         result[f"forward_{prec}"] = entry
     coarse.load_state_dict(state[0]); fine.load_state_dict(state[1])
     coarse.eval(); fine.eval()
     return result
+
+
+def measured_traffic(key: str):
+    """HBM bytes from the committed rocprofv3 counter passes (profiles/composite_traffic.json), keyed by the exact launch
+    / step shape they were taken at; None where no pass exists (the bench then reports ``traffic: null``)."""
+    path = os.path.join(ROOT, "profiles", "composite_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f).get(key)
 
 
 def timed_images(step, steps: int, warmup: int, barrier):

@@ -48,7 +48,7 @@ class FieldFn(torch.autograd.Function):
         blob = model.blob("bwd" if DATA_PRECISION == "fp32" else "bwd_x3")
         flat = ops.field_backward(g_raw, ctx.save, blob, model.ins_num, model.wgrad_index(), n_params,
                                   wgrad_precision=WGRAD_PRECISION, data_precision=DATA_PRECISION,
-                                  out=model.grad_buffer())      # a GradBucket's slice when one was adopted
+                                  out=model.lend_grad_buffer())  # a GradBucket's slice when one was adopted and is free
         ctx.save = None
         out: List = []
         at = 0

@@ -16,6 +16,8 @@
 // All arithmetic is fp32 (v_mfma_f32_32x32x2_f32).
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "../../include/dmnerf_hip.h"
 #include "field_common.h"
 #include "field_stream.h"
@@ -680,20 +682,30 @@ extern "C" int dmn_field_bwd_data(const float* g_raw, const float* save, const f
 namespace {
 // A second stream for the smallest weight-gradient GEMMs (25 KB of LDS, < 100 registers per wave): they fit into a CU
 // beside a workgroup of the ring kernel (128 KB of LDS, one wave per SIMD) and run in its shadow instead of behind it.
-// Fork / join by events; created once per device on first use.
+// Fork / join by events; created once per device on first use.  The stream and its event pair are shared by every caller
+// on the device: `mutex` serialises creation and each fork .. join sequence (record / wait pairs of two host threads must
+// not interleave); callers on different streams of one thread are ordered by the events themselves.
 struct SideStream {
   hipStream_t stream = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
+  bool ready = false;
+  std::mutex mutex;
 };
+// call with s.mutex held by nobody; returns with the device's entry created (or null: no side stream, run in line)
 SideStream* side_stream() {
   static SideStream per_device[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
   SideStream& s = per_device[dev];
-  if (s.stream == nullptr) {
-    if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) { s.stream = nullptr; return nullptr; }
-    if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(s.mutex);
+  if (!s.ready) {
+    if (s.stream == nullptr && hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) {
+      s.stream = nullptr;
+      return nullptr;
+    }
+    if (s.fork == nullptr && hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess) { s.fork = nullptr; return nullptr; }
+    if (s.join == nullptr && hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) { s.join = nullptr; return nullptr; }
+    s.ready = true;
   }
   return &s;
 }
@@ -732,6 +744,8 @@ extern "C" int dmn_field_bwd_weights(const float* save, const float* grad_record
 #define DMN_WG_SIDE 1
 #endif
     SideStream* side = x3 && DMN_WG_SIDE ? side_stream() : nullptr;
+    std::unique_lock<std::mutex> fork_join;              // held from fork to join (one caller at a time per device)
+    if (side != nullptr) fork_join = std::unique_lock<std::mutex>(side->mutex);
     hipStream_t st2 = st;
     if (side != nullptr && hipEventRecord(side->fork, st) == hipSuccess &&
         hipStreamWaitEvent(side->stream, side->fork, 0) == hipSuccess)
@@ -757,8 +771,10 @@ extern "C" int dmn_field_bwd_weights(const float* save, const float* grad_record
     const int dens[] = {16};
     launch_class<1, 8, 1, 4>(a, dens, 1, x3, st);
     if (st2 != st) {                                     // join: the reduction reads every partial sum
-      if (hipEventRecord(side->join, st2) != hipSuccess || hipStreamWaitEvent(st, side->join, 0) != hipSuccess)
+      if (hipEventRecord(side->join, st2) != hipSuccess || hipStreamWaitEvent(st, side->join, 0) != hipSuccess) {
+        hipStreamSynchronize(st2);                       // the side kernels still write the caller's workspace
         return DMN_ERR_LAUNCH;
+      }
     }
   }
   const long n = wgrad_index_len(T);

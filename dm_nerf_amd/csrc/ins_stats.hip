@@ -69,7 +69,8 @@ constexpr int kMaxLabel = 1024;
 
 // Ray-sharded training (bins > 0): the label set is the whole batch's.  hist_out != null: only this shard's histogram
 // over labels [0, bins) leaves (as floats, to be summed over the shards); hist_in != null: the classes come from that
-// summed histogram instead of this shard's own.
+// summed histogram instead of this shard's own.  Both buffers hold bins + 1 floats: entry [bins] is the out-of-range
+// flag, so that after the sum EVERY shard knows that some shard saw a label outside [0, bins) and takes the same branch.
 __global__ __launch_bounds__(1024) void ins_label_prep_kernel(const long* labels, long N, int Vmax, long* classes,
                                                               float* count, int* meta, const float* hist_in,
                                                               float* hist_out, int bins) {
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(1024) void ins_label_prep_kernel(const long* labels
   const int tid = threadIdx.x;
   const int limit = bins > 0 ? bins : kMaxLabel;
   hist[tid] = hist_in != nullptr && tid < bins ? (int)hist_in[tid] : 0;
-  if (tid == 0) bad = 0;
+  if (tid == 0) bad = hist_in != nullptr && hist_in[bins] != 0.f ? 1 : 0;
   __syncthreads();
   for (long i = tid; i < N; i += 1024) {
     const long l = labels[i];
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(1024) void ins_label_prep_kernel(const long* labels
   if (hist_out != nullptr) {
     if (tid < bins) hist_out[tid] = (float)hist[tid];
     if (tid == 0) {
+      hist_out[bins] = (float)bad;
       meta[0] = 0;
       meta[1] = bad;
     }
@@ -286,7 +288,11 @@ __device__ __forceinline__ int first_col(bool hit0, bool hit1) {    // lowest co
 // State in registers: lane l owns columns l, l + 64 (v, shortest path costs, path, row4col, position in scipy's `remaining`
 // order, visited flag) and rows l, l + 64 (u, col4row, visited flag); the chosen column / row is read from its owner by
 // v_readlane.  LDS holds the cost matrix and, once per row, the path costs for the dual update.
-__global__ __launch_bounds__(64) void ins_assign_kernel(const float* host_blob, int* meta, int K, int Vmax, int* match,
+// A failed assignment (labels the kernels do not take, a cost matrix without a finite matching) is reported per call and
+// per problem: every entry of that problem's matching is kNoAssignment, which the loss kernels test; the label meta is
+// shared by the calls of a step and cached across steps, so it stays read-only here.
+constexpr int kNoAssignment = -2;
+__global__ __launch_bounds__(64) void ins_assign_kernel(const float* host_blob, const int* meta, int K, int Vmax, int* match,
                                                         int cost_in_lds) {
   extern __shared__ float cmat[];                        // the V x K cost matrix (cost_in_lds; else read from global memory)
   __shared__ double spc_lds[kMaxCols];
@@ -377,11 +383,10 @@ __global__ __launch_bounds__(64) void ins_assign_kernel(const float* host_blob, 
       if (r == cur) break;
     }
   }
-  if (lane == 0 && failed) meta[1] = 1;
-  if (c0 < Vmax) match[c0] = (!failed && c0 < V) ? col4row0 : -1;
-  if (c1 < Vmax) match[c1] = (!failed && c1 < V) ? col4row1 : -1;
-  if (has0) match[Vmax + c0] = failed ? -1 : row4col0;
-  if (has1) match[Vmax + c1] = failed ? -1 : row4col1;
+  if (c0 < Vmax) match[c0] = failed ? kNoAssignment : (c0 < V ? col4row0 : -1);
+  if (c1 < Vmax) match[c1] = failed ? kNoAssignment : (c1 < V ? col4row1 : -1);
+  if (has0) match[Vmax + c0] = failed ? kNoAssignment : row4col0;
+  if (has1) match[Vmax + c1] = failed ? kNoAssignment : row4col1;
 }
 
 // loss terms for a matching: col_of[v] = column matched to class v (v < V), class_of[k] = class matched to column k or -1
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(64) void ins_loss_kernel(const float* cost, const f
                                                       int K, int Vmax, float* out) {
   const int V = meta[0];
   const int lane = threadIdx.x;
-  if (meta[1] != 0 || V <= 0 || V > Vmax) {          // no assignment (device-side matching on labels the kernels do not take)
+  if (meta[1] != 0 || V <= 0 || V > Vmax || col_of[0] == kNoAssignment) {   // no assignment (device-side matching failed)
     if (lane < 4) out[lane] = __builtin_nanf("");
     return;
   }
@@ -434,7 +439,7 @@ __global__ __launch_bounds__(256) void ins_loss_bwd_kernel(const float* stats, c
                                                            float* g_stats) {
   __shared__ int n_unmatched;
   const int V = meta[0];
-  if (meta[1] != 0 || V <= 0 || V > Vmax) {
+  if (meta[1] != 0 || V <= 0 || V > Vmax || class_of[0] == kNoAssignment) {
     for (int e = threadIdx.x; e < 3 * Vmax * K; e += 256) g_stats[e] = 0.f;
     return;
   }
@@ -532,7 +537,7 @@ extern "C" int dmn_ins_cost(const double* partial, float* stats, const float* co
   return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
 }
 
-extern "C" int dmn_ins_assign(const float* host_blob, int* meta, int n_cols, int max_classes, int* match, int problems,
+extern "C" int dmn_ins_assign(const float* host_blob, const int* meta, int n_cols, int max_classes, int* match, int problems,
                               void* stream) {
   if (n_cols <= 0 || n_cols > kMaxCols || max_classes <= 0 || max_classes > kMaxCols || problems <= 0) return DMN_ERR_BAD_ARG;
   if (!host_blob || !meta || !match) return DMN_ERR_BAD_ARG;

@@ -80,6 +80,7 @@ class DM_NeRF(nn.Module):
         self._indices = {}               # (flavour, device) -> gather table
         self._flat = None                # (key, parameters as one flat vector) of the last blob packed
         self._grad_flat = None           # persistent flat gradient buffer (parallel.GradBucket hands out slices)
+        self._grad_lent = False          # the buffer is the output of a backward node of the running backward pass
 
     # ---- packed weights -------------------------------------------------------------------
     def _ordered_params(self) -> List[torch.Tensor]:
@@ -129,14 +130,32 @@ class DM_NeRF(nn.Module):
         self._grad_flat = flat
 
     def grad_buffer(self):
-        """The adopted flat gradient buffer if the kernel may write it now (no parameter holds a gradient yet that
-        lives in it or would have to be accumulated into), else None."""
+        """The adopted flat gradient buffer if the kernel may write it now, else None: no parameter holds a gradient
+        yet (one that lives in the buffer or would have to be accumulated into), and no other backward node of the
+        running backward pass has been handed the buffer.  The second condition matters when this module is applied
+        twice in one graph (two ray batches summed into one loss): the engine sums the two nodes' gradients only after
+        both have run, ``p.grad`` is still None when the second one asks, and a second in-place write would replace the
+        first node's result inside the engine's input buffer (g2 + g2 instead of g1 + g2).  The lending ends with the
+        backward pass (``lend_grad_buffer``)."""
         flat = self._grad_flat
-        if flat is None or flat.device != self._ordered_params()[0].device:
+        if flat is None or self._grad_lent or flat.device != self._ordered_params()[0].device:
             return None
         if any(p.grad is not None for p in self.parameters()):
             return None
         return flat
+
+    def lend_grad_buffer(self):
+        """``grad_buffer()`` for a backward node that is going to return views of it: marks the buffer as handed out
+        until the engine has finished the running backward pass (by then the gradients have been accumulated into
+        ``p.grad``, which is what ``grad_buffer`` looks at from there on)."""
+        flat = self.grad_buffer()
+        if flat is not None:
+            self._grad_lent = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._return_grad_buffer)
+        return flat
+
+    def _return_grad_buffer(self):
+        self._grad_lent = False
 
     def invalidate_blobs(self) -> None:
         """Drop the packed-weight cache (needed only after parameter writes through ``.data``, see ``blob``)."""

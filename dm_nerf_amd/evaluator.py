@@ -83,7 +83,8 @@ class _InsCriterionFn(torch.autograd.Function):
             classes = torch.empty(n, dtype=torch.int64, device=dev)
             count = torch.empty(ins_num, dtype=torch.float32, device=dev)
             meta = torch.empty(2, dtype=torch.int32, device=dev)
-            hist = torch.empty(ins_num + 1, dtype=torch.float32, device=dev)
+            # ins_num + 1 label bins and, last, the label-out-of-range flag: summed with the bins, it is the same on every rank
+            hist = torch.empty(ins_num + 2, dtype=torch.float32, device=dev)
             check(lib.dmn_ins_label_hist(ptr(labels), n, ins_num + 1, ptr(hist), ptr(meta), st), "dmn_ins_label_hist")
             hist = reduce("ins_label_count", hist).contiguous()
             check(lib.dmn_ins_label_slots(ptr(labels), n, ptr(hist), ins_num + 1, ins_num, ptr(classes), ptr(count),
@@ -110,6 +111,9 @@ class _InsCriterionFn(torch.autograd.Function):
         else:
             host = blob.cpu().numpy()                                                 # the one wait for the device
             v = int(host[0, 0])
+            if reduce is not None and host[0, 1] != 0.0:
+                # the flag was summed with the histogram: every rank is here, none re-enters the collectives
+                raise ValueError("sharded ins_criterion needs labels in [0, ins_num] on every shard")
             if host[0, 1] != 0.0 or v == 0:
                 return (None,) * (4 * m)
             match = np.full((m, ins_num + k), -1, dtype=np.int32)

@@ -237,8 +237,9 @@ int dmn_ins_stats_bwd(const float* pred, const long* classes, long n_rays, int n
  *   dmn_ins_loss        out4 = {sum, valid_ce, invalid_ce, valid_siou} (:27-37) for col_of [max_classes] / class_of [n_cols]
  *   dmn_ins_loss_bwd    g_stats [3][max_classes][n_cols] from the upstream gradients of the four outputs (NULL = 0)
  * Ray-sharded training (the label set, the statistics and the ray count are the whole batch's; the caller sums them over
- * the shards between the calls): dmn_ins_label_hist (this shard's histogram over labels [0, bins) as floats),
- * dmn_ins_label_slots (classes / counts from the summed histogram), dmn_ins_stats_sum (partial -> stats, then
+ * the shards between the calls): dmn_ins_label_hist (this shard's histogram over labels [0, bins) as floats; `hist`
+ * holds bins + 1 floats, the last one is this shard's label-out-of-range flag so that the summed flag is every shard's),
+ * dmn_ins_label_slots (classes / counts from the summed histogram [bins + 1]), dmn_ins_stats_sum (partial -> stats, then
  * dmn_ins_cost with partial = NULL), n_rays_dev = the summed ray count on the device (NULL: n_rays).              */
 int dmn_ins_label_prep(const long* labels, long n_rays, int max_classes, long* classes, float* count, int* meta,
                        void* stream);
@@ -253,9 +254,10 @@ int dmn_ins_cost(const double* partial, float* stats, const float* count, const 
                  const float* n_rays_dev, int n_cols, int max_classes, float* cost, float* colsum, float* host_blob,
                  void* stream);
 /* The assignment on the device instead of scipy on the host (same algorithm, fp64, scipy's choice among equal
- * candidates): host_blob as dmn_ins_cost wrote it -> match = {col_of [max_classes], class_of [n_cols]}; sets meta[1] where
- * no assignment exists (the loss terms are then computed on -1 entries: the caller checks meta when it next may wait). */
-int dmn_ins_assign(const float* host_blob, int* meta, int n_cols, int max_classes, int* match, int problems,
+ * candidates): host_blob as dmn_ins_cost wrote it -> match = {col_of [max_classes], class_of [n_cols]} per problem.  Where
+ * no assignment exists (labels outside the kernels' table, no finite matching) every entry of that problem's match is -2;
+ * dmn_ins_loss then returns NaN terms and dmn_ins_loss_bwd zeros.  meta is read-only (it is shared between calls). */
+int dmn_ins_assign(const float* host_blob, const int* meta, int n_cols, int max_classes, int* match, int problems,
                    void* stream);      /* `problems` blobs / match arrays back to back, one workgroup each */
 int dmn_ins_loss(const float* cost, const float* colsum, const int* col_of, const int* class_of, const int* meta,
                  long n_rays, const float* n_rays_dev, int n_cols, int max_classes, float* out4, void* stream);

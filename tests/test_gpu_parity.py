@@ -1070,7 +1070,12 @@ class _TwoShardReducer:
             self.own.append((tag, t.detach().clone()))
             # the label set shapes the statistics (one row per label present anywhere): the recording pass must
             # already see the whole batch's
-            return self.known[tag].to(t.device) if tag in self.known else t
+            if tag not in self.known:
+                return t
+            k = self.known[tag].to(t.device)
+            if k.numel() + 1 == t.numel():          # the kernels' histogram carries the out-of-range flag as a last entry
+                k = torch.cat([k, k.new_zeros(1)])
+            return k
         tag2, rec = self.other[self.calls]
         assert tag2 == tag
         self.calls += 1
@@ -1157,6 +1162,67 @@ def test_grad_bucket_receives_the_weight_gradients_in_place():
         raw = dm.autograd.FieldFn.apply(G(o), G(d), z, coarse, "fp32", *coarse.parameters())
         raw.sum().backward(retain_graph=True)
         raw.sum().backward()
+
+
+def test_grad_bucket_with_one_model_applied_twice_in_one_graph():
+    """Two ray batches through the SAME networks, summed into one loss, under a GradBucket: the engine sums the two
+    field nodes' parameter gradients only after both backward nodes have run, so the second node must not be handed the
+    bucket's buffer while the first node's result lives in it (it would be overwritten in place: g2 + g2).  The
+    gradients must equal the bucket-less ones, and the lending must end with the backward pass (the next step writes
+    in place again)."""
+    from dm_nerf_amd.parallel import GradBucket
+    pos, view, coarse, fine, args = nets(13, 0, 1)
+    coarse.train(); fine.train()
+    o, d, t_rand, u = cases.path_rays(32, seed=29)
+    z = dm.z_val_sample(16, cases.NEAR, cases.FAR, 64)
+
+    def backward():
+        total = 0.0
+        for k, sl in enumerate((slice(0, 16), slice(16, 32))):
+            a = SimpleNamespace(**{**vars(args), "perturb": 1.0, "is_train": True, "t_rand": G(t_rand[sl]), "u": G(u[sl])})
+            out = dm.dm_nerf(G(np.stack([o[sl], d[sl]], 0)), pos, view, coarse, fine, z, a)
+            total = total + (1.0 + k) * (out["rgb_fine"].sum() + out["rgb_coarse"].sum() + out["ins_fine"].sum())
+        total.backward()
+
+    def clear():
+        for m in (coarse, fine):
+            for p in m.parameters():
+                p.grad = None
+
+    backward()
+    plain = torch.cat([p.grad.reshape(-1) for m in (coarse, fine) for p in m.parameters()]).clone()
+    clear()
+    bucket = GradBucket([coarse, fine])
+    for step in range(2):
+        clear()
+        bucket.flat.fill_(float("nan"))
+        backward()
+        assert not coarse._grad_lent and not fine._grad_lent             # returned at the end of the backward pass
+        bucket._collect()                                                # what allreduce() does first
+        assert rel_err(H(bucket.flat), H(plain)) < 1e-6, step
+    # and a single application still lands in place afterwards
+    clear()
+    a = SimpleNamespace(**{**vars(args), "perturb": 1.0, "is_train": True, "t_rand": G(t_rand[:16]), "u": G(u[:16])})
+    out = dm.dm_nerf(G(np.stack([o[:16], d[:16]], 0)), pos, view, coarse, fine, z, a)
+    out["rgb_fine"].sum().backward()
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views))
+
+
+def test_assignment_failure_is_per_call_and_leaves_the_label_cache_usable():
+    """assign="device" on a cost matrix without a finite matching (a NaN prediction): that call returns NaN terms; the
+    label classes cached for the labels tensor are untouched, so the next call on the same labels is the normal one."""
+    n, ins_num = 64, 13
+    pred, labels = cases.criterion_case(n, ins_num, (0, 2, 3, 7, 12), 313)
+    lab = torch.from_numpy(labels).to(DEV)
+    good = dm.ins_criterion(G(pred), lab, ins_num, assign="device")
+    bad_pred = pred.copy()
+    bad_pred[:] = np.nan                                                     # no finite path cost anywhere
+    bad = dm.ins_criterion(G(bad_pred), lab, ins_num, assign="device")
+    assert not np.isfinite(float(bad[0]))
+    again = dm.ins_criterion(G(pred), lab, ins_num, assign="device")
+    host = dm.ins_criterion(G(pred), lab, ins_num, assign="host")
+    for a, b, c in zip(good, again, host):
+        assert float(a) == float(b) == float(c)
 
 
 # ---- training ray selectors (row N1) --------------------------------------------------------------------

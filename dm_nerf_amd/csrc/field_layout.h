@@ -161,6 +161,40 @@ constexpr long kX3BlobBytes = (long)kConstFloats * 4 + kX3StreamHalfs * 2;
 constexpr long kX3IndexLen = (long)kConstFloats + kX3StreamHalfs;   // one gather entry per float / half
 
 // =====================================================================================
+// Full-precision bf16 ("x6") blob: same const section (fp32); every weight as THREE bf16 planes
+//   w = hi + mid + lo exactly   (hi = bf16(w), mid = bf16(w - hi), lo = w - hi - mid: 8 + 8 + 8 significand bits and
+//   the signs of the residuals cover fp32's 24),
+// for the 6-MFMA product  W*X = Whi*Xhi + Whi*Xmid + Wmid*Xhi + Wmid*Xmid + Whi*Xlo + Wlo*Xhi  on
+// v_mfma_f32_32x32x16_bf16 with X split the same way in the kernel (the three dropped terms are each below 2^-24 of the
+// product).  field_fwd_x6.hip walks k-steps in the OUTER loop (all output tiles of a layer accumulate at once, as the
+// exact-fp32 kernel does), so per layer: for k-step ks: for tile t: [hi, mid, lo] chunks;
+// chunk[lane][j] = W_plane[32*t + (lane&31)][col(8*ks + j, lane>>5)], 64 lanes x 8 bf16 = 1 KiB (the x3 chunk).
+// 48 chunks = one 48 KiB stage = 2 k-steps of an 8-tile layer / 4 k-steps of a 4-tile layer / 8 or 4 k-steps of
+// ins_linear's T tiles; every layer is padded to whole stages.
+// =====================================================================================
+constexpr int kX6StageChunks = 48;
+constexpr int kX6StageBytes = kX6StageChunks * 1024;
+DMN_HD constexpr int x6_ksteps_per_stage(int n_tiles) { return kX6StageChunks / (3 * n_tiles); }   // 8 tiles: 2, 4: 4
+DMN_HD constexpr int x6_inso_ksteps_per_stage(int T) { return T <= 2 ? 8 : 4; }
+DMN_HD constexpr int x6_inso_stages(int T) { return 8 / x6_inso_ksteps_per_stage(T); }
+constexpr int kX6StageL0 = 0;      // 4 k-steps x 8 tiles              -> 2 stages
+constexpr int kX6StageL1 = 2;      // mlps.1..4: 16 k-steps            -> 8 stages each
+constexpr int kX6StageL5 = 34;     // 16 + 4 k-steps                   -> 10 stages
+constexpr int kX6StageL6 = 44;     // mlps.6, mlps.7
+constexpr int kX6StageRgbF = 60;   // rgb_feature_linear               8
+constexpr int kX6StageRgbH = 68;   // 4 tiles x (16 + 2) k-steps       -> 5 stages (the last one half used)
+constexpr int kX6StageInsF = 73;   // ins_feature_linear               8
+constexpr int kX6StageInsH = 81;   // 4 tiles x 16 k-steps             -> 4 stages
+constexpr int kX6StageInsO = 85;   // T tiles x 8 k-steps              -> 1 or 2 stages
+DMN_HD constexpr int x6_total_stages(int T) { return kX6StageInsO + x6_inso_stages(T); }
+DMN_HD constexpr int x6_mlp_stage(int l) {
+  return l == 0 ? kX6StageL0 : (l <= 4 ? kX6StageL1 + 8 * (l - 1) : (l == 5 ? kX6StageL5 : kX6StageL6 + 8 * (l - 6)));
+}
+DMN_HD constexpr long x6_stream_halfs(int T) { return (long)x6_total_stages(T) * kX6StageChunks * kX3ChunkHalfs; }
+DMN_HD constexpr long x6_blob_bytes(int ins_num) { return (long)kConstFloats * 4 + x6_stream_halfs(ins_tiles(ins_num)) * 2; }
+DMN_HD constexpr long x6_index_len(int ins_num) { return (long)kConstFloats + x6_stream_halfs(ins_tiles(ins_num)); }
+
+// =====================================================================================
 // Training (backward of the field; train_dmsr.py:32-64 drives it through autograd).
 //
 // Per-point state crosses HBM as "register images": what a wave of the field kernels holds for its 32

@@ -115,7 +115,69 @@ void layer_x3(int32_t* stream, int stage0, int n_tiles, int n_ksteps, int w_off,
       }
 }
 
+// ---- full-precision bf16 stream ("x6": three bf16 planes per weight, k-steps in the outer loop) ----------------
+// One layer: for k-step ks, for tile t: [hi, mid, lo] chunks; kps k-steps per 48-chunk stage (field_layout.h).
+// All three chunks of a (k-step, tile) carry the same gather entries: the plane is the chunk's position modulo 3.
+template <class Col>
+void layer_x6(int32_t* stream, int stage0, int n_tiles, int n_ksteps, int kps, int w_off, int fan_in, int n_rows, Col col) {
+  for (int ks = 0; ks < n_ksteps; ++ks)
+    for (int t = 0; t < n_tiles; ++t)
+      for (int plane = 0; plane < 3; ++plane) {
+        long chunk = (long)(stage0 + ks / kps) * kX6StageChunks + (long)((ks % kps) * n_tiles + t) * 3 + plane;
+        int32_t* c = stream + chunk * kX3ChunkHalfs;
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            int row = 32 * t + (lane & 31);
+            int k = col(8 * ks + j, lane >> 5);
+            c[lane * 8 + j] = (k < 0 || row >= n_rows) ? -1 : w_off + row * fan_in + k;
+          }
+      }
+}
+
 }  // namespace
+
+extern "C" long dmn_field_blob_x6_bytes(int ins_num) {
+  if (!supported(ins_num)) return DMN_ERR_BAD_ARG;
+  return x6_blob_bytes(ins_num);
+}
+
+extern "C" long dmn_field_pack_index_x6_len(int ins_num) {
+  if (!supported(ins_num)) return DMN_ERR_BAD_ARG;
+  return x6_index_len(ins_num);
+}
+
+extern "C" int dmn_field_pack_index_x6(int ins_num, int32_t* index_out) {
+  if (!index_out || !supported(ins_num)) return DMN_ERR_BAD_ARG;
+  const int T = ins_tiles(ins_num);
+  const ParamOffsets P = param_offsets(ins_num);
+  std::fill(index_out, index_out + x6_index_len(ins_num), -1);
+  fill_const(index_out, P, ins_num);
+  int32_t* s = index_out + kConstFloats;
+  auto act = [](int i, int h) { return feat_of(i, h); };
+  const int k8 = x6_ksteps_per_stage(8), k4 = x6_ksteps_per_stage(4);
+
+  layer_x6(s, kX6StageL0, 8, 4, k8, P.mlp_w[0], kPosCh, kWidth, [](int i, int h) { return pos_slot(i, h); });
+  for (int l = 1; l < kDepth; ++l) {
+    if (l == kSkipLayer)                                           // cat([h, input_pts]) (dm_nerf.py:87)
+      layer_x6(s, x6_mlp_stage(l), 8, 20, k8, P.mlp_w[l], mlp_fan_in(l), kWidth, [](int i, int h) {
+        if (i < 128) return feat_of(i, h);
+        int p = pos_slot(i - 128, h);
+        return p < 0 ? -1 : kWidth + p;
+      });
+    else
+      layer_x6(s, x6_mlp_stage(l), 8, 16, k8, P.mlp_w[l], kWidth, kWidth, act);
+  }
+  layer_x6(s, kX6StageRgbF, 8, 16, k8, P.rgbf_w, kWidth, kWidth, act);
+  layer_x6(s, kX6StageRgbH, 4, 18, k4, P.rgbh_w, kWidth + kDirCh, kHalf, [](int i, int h) {   // cat([feature, dirs])
+    if (i < 128) return feat_of(i, h);
+    int p = dir_slot(i - 128, h);
+    return p < 0 ? -1 : kWidth + p;
+  });
+  layer_x6(s, kX6StageInsF, 8, 16, k8, P.insf_w, kWidth, kWidth, act);
+  layer_x6(s, kX6StageInsH, 4, 16, k4, P.insh_w, kWidth, kHalf, act);
+  layer_x6(s, kX6StageInsO, T, 8, x6_inso_ksteps_per_stage(T), P.inso_w, kHalf, ins_num + 1, act);
+  return DMN_OK;
+}
 
 extern "C" int dmn_field_param_floats(int ins_num) {
   if (!supported(ins_num)) return DMN_ERR_BAD_ARG;

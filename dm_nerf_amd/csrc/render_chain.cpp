@@ -36,11 +36,12 @@ extern "C" int dmn_render_rays(const float* rays_o, const float* rays_d, const f
     zs = S;
   }
   auto field = [&](const float* z, long stride, int n_s, const void* blob, float* raw) {
-    return precision == DMN_PREC_FP32
-               ? dmn_field_fwd_rays(rays_o, rays_d, z, stride, n_rays, n_s, static_cast<const float*>(blob), ins_num,
-                                    raw, stream)
-               : dmn_field_fwd_rays_x3(rays_o, rays_d, z, stride, n_rays, n_s, blob, ins_num, precision, raw, status,
-                                       stream);
+    if (precision == DMN_PREC_FP32)
+      return dmn_field_fwd_rays(rays_o, rays_d, z, stride, n_rays, n_s, static_cast<const float*>(blob), ins_num, raw,
+                                stream);
+    if (precision == DMN_PREC_BF16X6)
+      return dmn_field_fwd_rays_x6(rays_o, rays_d, z, stride, n_rays, n_s, blob, ins_num, 0, raw, stream);
+    return dmn_field_fwd_rays_x3(rays_o, rays_d, z, stride, n_rays, n_s, blob, ins_num, precision, raw, status, stream);
   };
   if ((rc = field(zc, zs, S, blob_coarse, raw_c)) != DMN_OK) return rc;
   if ((rc = dmn_composite_fwd(raw_c, zc, zs, rays_d, n_rays, S, C, 0, rgb_coarse, w_c, depth_coarse, ins_coarse,

@@ -100,11 +100,11 @@ class DM_NeRF(nn.Module):
         cached = self._blobs.get(precision)
         if cached is not None and cached[0] == key:
             return cached[1]
-        flavour = precision if precision in ("fp32", "bwd", "bwd_x3") else "x3"
+        flavour = precision if precision in ("fp32", "bwd", "bwd_x3") else ("x6" if precision == "bf16x6" else "x3")
         index = self._indices.get((flavour, dev))
         if index is None:
             make = {"fp32": ops.pack_index, "bwd": ops.bwd_pack_index, "bwd_x3": ops.bwd_pack_index_x3,
-                    "x3": ops.pack_index_x3}[flavour]
+                    "x3": ops.pack_index_x3, "x6": ops.pack_index_x6}[flavour]
             index = self._indices[(flavour, dev)] = make(self.ins_num, dev)
         if self._flat is not None and self._flat[0] == key:      # the backward's blob follows the forward's: one gather
             flat = self._flat[1]
@@ -114,6 +114,8 @@ class DM_NeRF(nn.Module):
             self._flat = (key, flat)
         if flavour == "x3":
             blob = ops.pack_blob_x3(flat, index, self.ins_num, precision)
+        elif flavour == "x6":
+            blob = ops.pack_blob_x6(flat, index, self.ins_num)
         elif flavour == "bwd_x3":
             blob = ops.pack_bwd_blob_x3(flat, index, self.ins_num)
         else:

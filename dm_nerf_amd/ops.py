@@ -15,7 +15,8 @@ from ._lib import check, current_stream, load, ptr
 MAX_INS_CHANNELS = 128
 
 # arithmetic of the field kernel (include/dmnerf_hip.h DMN_PREC_*)
-PRECISIONS = {"fp32": 0, "fp16x3": 1, "bf16x3": 2}
+PRECISIONS = {"fp32": 0, "fp16x3": 1, "bf16x3": 2, "bf16x6": 3}
+X3_PRECISIONS = ("fp16x3", "bf16x3")        # two-way split kernels (16 operand bits); "bf16x6" carries all 24
 STATUS_FP16_RANGE = 1
 _status = {}
 
@@ -141,6 +142,26 @@ def pack_blob_x3(flat_params: torch.Tensor, index: torch.Tensor, ins_num: int, p
     return blob
 
 
+def pack_index_x6(ins_num: int, device) -> torch.Tensor:
+    lib = load()
+    n = lib.dmn_field_pack_index_x6_len(ins_num)
+    if n < 0:
+        raise ValueError(f"ins_num={ins_num} unsupported (ins_num + 1 must be <= {MAX_INS_CHANNELS})")
+    idx = np.empty(n, dtype=np.int32)
+    check(lib.dmn_field_pack_index_x6(ins_num, idx.ctypes.data), "dmn_field_pack_index_x6")
+    return torch.from_numpy(idx).to(device)
+
+
+def pack_blob_x6(flat_params: torch.Tensor, index: torch.Tensor, ins_num: int) -> torch.Tensor:
+    """Blob of the full-precision bf16 kernel: every weight as its exact hi / mid / lo bf16 planes."""
+    _dev(flat_params, "flat_params")
+    n_bytes = load().dmn_field_blob_x6_bytes(ins_num)
+    blob = torch.empty(n_bytes, dtype=torch.uint8, device=flat_params.device)
+    check(load().dmn_field_pack_x6(ptr(flat_params), ptr(index), ins_num, ptr(blob), current_stream()),
+          "dmn_field_pack_x6")
+    return blob
+
+
 def raygen(H: int, W: int, K, c2w) -> Tuple[torch.Tensor, torch.Tensor]:
     """get_rays_k; K: 3x3/4x4 array-like (host), c2w: 3x4/4x4 (host array or tensor)."""
     K = np.asarray(K, dtype=np.float64)
@@ -195,10 +216,10 @@ def encode(x: torch.Tensor, n_freqs: int) -> torch.Tensor:
 
 def field_rays(rays_o: torch.Tensor, rays_d: torch.Tensor, z: torch.Tensor, blob: torch.Tensor,
                ins_num: int, precision: str = "fp32", sigma_only: bool = False) -> torch.Tensor:
-    """raw [N,S,5+ins_num] of the field on ``o + d*z``.  ``sigma_only`` (split-precision kernels): evaluate the trunk
-    and the density head only -- raw[..., 3] is filled, every other channel is zero."""
+    """raw [N,S,5+ins_num] of the field on ``o + d*z``.  ``sigma_only`` (bf16 / fp16 matrix-pipe kernels): evaluate the
+    trunk and the density head only -- raw[..., 3] is filled, every other channel is zero."""
     if sigma_only and precision == "fp32":
-        raise ValueError("sigma_only is a mode of the split-precision kernels ('fp16x3' / 'bf16x3')")
+        raise ValueError("sigma_only is a mode of the 16-bit matrix-pipe kernels ('fp16x3' / 'bf16x3' / 'bf16x6')")
     n = rays_o.shape[0]
     rays_o = _dev(rays_o, "rays_o").contiguous()
     rays_d = _dev(rays_d, "rays_d").contiguous()
@@ -209,6 +230,9 @@ def field_rays(rays_o: torch.Tensor, rays_d: torch.Tensor, z: torch.Tensor, blob
         if precision == "fp32":
             check(load().dmn_field_fwd_rays(ptr(rays_o), ptr(rays_d), ptr(zz), stride, n, s, ptr(blob), ins_num,
                                             ptr(raw), current_stream()), "dmn_field_fwd_rays")
+        elif precision == "bf16x6":
+            check(load().dmn_field_fwd_rays_x6(ptr(rays_o), ptr(rays_d), ptr(zz), stride, n, s, ptr(blob), ins_num,
+                                               int(sigma_only), ptr(raw), current_stream()), "dmn_field_fwd_rays_x6")
         else:
             fn = load().dmn_field_fwd_rays_x3_sigma if sigma_only else load().dmn_field_fwd_rays_x3
             check(fn(ptr(rays_o), ptr(rays_d), ptr(zz), stride, n, s, ptr(blob), ins_num, precision_code(precision),
@@ -336,6 +360,9 @@ def field_embedded(embedded: torch.Tensor, blob: torch.Tensor, ins_num: int, pre
     if precision == "fp32":
         check(load().dmn_field_fwd_embedded(ptr(flat), flat.shape[0], ptr(blob), ins_num, ptr(raw),
                                             current_stream()), "dmn_field_fwd_embedded")
+    elif precision == "bf16x6":
+        check(load().dmn_field_fwd_embedded_x6(ptr(flat), flat.shape[0], ptr(blob), ins_num, ptr(raw),
+                                               current_stream()), "dmn_field_fwd_embedded_x6")
     else:
         check(load().dmn_field_fwd_embedded_x3(ptr(flat), flat.shape[0], ptr(blob), ins_num,
                                                precision_code(precision), ptr(raw), ptr(status_word(raw.device)),
@@ -371,7 +398,7 @@ def fused_supported(n_samples: int, n_importance: int, ins_num: int, precision: 
     """Whether ``render_fused`` covers this configuration: split-precision kernels, 64-sample passes, and the coarse
     launch's resampling scratch -- (4 * n_samples + n_importance) floats per ray -- inside its 8 KB of LDS (the same
     bound ``dmn_field_composite_x3`` checks; beyond it the image loop takes the chained kernels)."""
-    return (precision in ("fp16x3", "bf16x3") and n_samples % 64 == 0 and (n_samples + n_importance) % 64 == 0
+    return (precision in X3_PRECISIONS and n_samples % 64 == 0 and (n_samples + n_importance) % 64 == 0
             and n_samples >= 64 and 0 <= n_importance <= 1024 and 4 * n_samples + n_importance <= FUSED_SCRATCH_FLOATS
             and ins_num + 1 <= MAX_INS_CHANNELS)
 

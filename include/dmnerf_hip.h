@@ -35,6 +35,8 @@ extern "C" {
 #define DMN_PREC_FP32 0    /* v_mfma_f32_32x32x2_f32: exact fp32 products (parity mode) */
 #define DMN_PREC_FP16X3 1  /* 3 x v_mfma_f32_32x32x16_f16 per product on hi/lo fp16 splits (~1e-6 rel.) */
 #define DMN_PREC_BF16X3 2  /* 3 x v_mfma_f32_32x32x16_bf16 per product on hi/lo bf16 splits (~1e-5 rel.) */
+#define DMN_PREC_BF16X6 3  /* 6 x v_mfma_f32_32x32x16_bf16 per product on EXACT hi/mid/lo bf16 splits of both operands:
+                              all 24 significand bits of the fp32 operands enter the products (fp32-grade arithmetic) */
 /* bits of the sticky status word the split-precision kernels OR into */
 #define DMN_STATUS_FP16_RANGE 1  /* an activation left the fp16 range: re-run with another precision */
 
@@ -109,6 +111,22 @@ int dmn_field_fwd_rays_x3_sigma(const float* rays_o, const float* rays_d, const 
                                 long n_rays, int n_samples, const void* blob, int ins_num, int precision, float* raw,
                                 int* status, void* stream);
 
+/* Full-precision flavour on the bf16 matrix pipe (DMN_PREC_BF16X6; csrc/field_fwd_x6.hip): same reference lines and
+ * outputs as dmn_field_fwd_rays / dmn_field_fwd_embedded.  Every fp32 operand is split exactly into three bf16 values
+ * (8 + 8 + 8 significand bits) and the product is the sum of the six partial products above 2^-24 of it, accumulated in
+ * fp32 -- no operand bit is dropped, so the deviation from the reference is the rounding noise of fp32 accumulation, as
+ * for the exact-fp32 MFMA kernel (tests/test_gpu_parity.py measures both against an fp64 evaluation).  `blob` is the x6
+ * blob (three bf16 planes per weight: dmn_field_blob_x6_bytes / dmn_field_pack_index_x6 / dmn_field_pack_x6).
+ * sigma_only != 0: the trunk and density_linear only, as dmn_field_fwd_rays_x3_sigma.                              */
+long dmn_field_blob_x6_bytes(int ins_num);
+long dmn_field_pack_index_x6_len(int ins_num);
+int dmn_field_pack_index_x6(int ins_num, int32_t* index_out);
+int dmn_field_pack_x6(const float* params, const int32_t* index, int ins_num, void* blob, void* stream);
+int dmn_field_fwd_rays_x6(const float* rays_o, const float* rays_d, const float* z, long z_ray_stride, long n_rays,
+                          int n_samples, const void* blob, int ins_num, int sigma_only, float* raw, void* stream);
+int dmn_field_fwd_embedded_x6(const float* embedded, long n_points, const void* blob, int ins_num, float* raw,
+                              void* stream);
+
 /* ---- field evaluation + compositing (+ resampling) fused: `raw` never reaches memory ----------------------
  * For the image loop (networks/tester.py:62-76 keeps rgb_fine / ins_fine only).  One launch evaluates the field of
  * `precision` (split-precision kernels: DMN_PREC_FP16X3 / DMN_PREC_BF16X3) on o + d*z, composites every ray as
@@ -135,7 +153,7 @@ int dmn_render_fused(const float* rays_o, const float* rays_d, const float* z_co
  * (stratified jitter with t_rand, or none when NULL ->) coarse field -> compositing -> inverse-CDF resampling
  * (draws u, or the det = True lattice when NULL) + sorted merge -> fine field -> compositing, all enqueued on
  * `stream`.  z_coarse is the caller's depth lattice as in the reference's signature (z_vals_coarse).  blobs are
- * the packed weights of `precision` (dmn_field_pack / dmn_field_pack_x3).  workspace: dmn_render_workspace_floats()
+ * the packed weights of `precision` (dmn_field_pack / _x3 / _x6).  workspace: dmn_render_workspace_floats()
  * floats laid out [z_coarse n*S | raw_coarse n*S*C | weights_coarse n*S | z_vals_fine n*(S+Ni) | raw_fine n*(S+Ni)*C],
  * C = 5 + ins_num -- the raw_* / z_vals_* entries of the reference's result dict.  Coarse outputs may be NULL.   */
 long dmn_render_workspace_floats(long n_rays, int n_samples, int n_importance, int ins_num);

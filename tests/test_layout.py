@@ -321,3 +321,171 @@ def test_x3_blob_consumed_in_mfma_order_equals_oracle_field(ins_num, seed):
     assert set(np.unique(used)) <= {0, 2}
     both = np.bincount(idx[idx >= 0], minlength=flat.size)
     assert both.min() >= 1
+
+
+# ---------------------------------------------------------------------------------------------
+# full-precision bf16 ("x6") blob: three exact bf16 planes per weight, k-steps in the outer loop, 48-chunk stages
+# (csrc/field_layout.h "x6", csrc/field_fwd_x6.hip).  The model below walks the stream the way the kernel does, splits
+# the activations the way the kernel does (round to nearest even to bf16, exact residuals) and sums the kernel's six
+# partial products -- in fp64, so that what is measured is the arithmetic's own error: the three dropped products.
+# ---------------------------------------------------------------------------------------------
+X6_STAGE = {"l0": 0, "l1": 2, "l5": 34, "l6": 44, "rgbf": 60, "rgbh": 68, "insf": 73, "insh": 81, "inso": 85}
+X6_STAGE_CHUNKS = 48
+
+
+def bf16_rne(x):
+    """float32 array -> nearest-even bf16 value, as float32 (what v_cvt_pk_bf16_f32 and a cast to __bf16 give)."""
+    b = np.asarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    b = (b + 0x7FFF + ((b >> 16) & 1)) & 0xFFFF0000
+    return b.astype(np.uint32).view(np.float32)
+
+
+def split3(x):
+    x = np.asarray(x, dtype=np.float32)
+    hi = bf16_rne(x)
+    r1 = x - hi
+    mid = bf16_rne(r1)
+    lo = bf16_rne(r1 - mid)
+    return hi, mid, lo
+
+
+def test_three_way_bf16_split_is_exact():
+    """hi + mid + lo == x bit for bit over the magnitudes the field sees (weights 1e-4 .. 30, activations to 7.7e3) and
+    far beyond, and the residuals really are bf16 values: nothing of an fp32 operand is dropped by the x6 kernels'
+    split.  (The one exception is the last binade below overflow: a value within 2^-9 of FLT_MAX rounds to a bf16
+    infinity -- 3.39e38 is the largest value the split takes.)"""
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal(200000) * np.exp(rng.uniform(-12, 9, 200000))).astype(np.float32)
+    x[:8] = [0.0, -0.0, 1.0, -1.0, 1.9999999, 255.99998, 1e-30, -3.38e38]
+    hi, mid, lo = split3(x)
+    assert np.array_equal((hi.astype(np.float64) + mid + lo).astype(np.float32), x)
+    assert np.array_equal(hi.astype(np.float64) + mid.astype(np.float64) + lo.astype(np.float64), x.astype(np.float64))
+    for plane in (hi, mid, lo):
+        assert np.all(plane.view(np.uint32) & 0xFFFF == 0)
+    # the six kept products against the exact one: each dropped term is below 2^-24 of |w x| (|mid| <= 2^-8 |x|,
+    # |lo| <= 2^-16 |x|), all three together below 2^-23 and ~2^-26 in the root mean square -- the size of ONE fp32
+    # rounding of the product, where an fp32 dot product of k terms carries k roundings of its partial sums
+    w = (rng.standard_normal(200000) * np.exp(rng.uniform(-9, 3, 200000))).astype(np.float32)
+    wh, wm, wl = (p.astype(np.float64) for p in split3(w))
+    xh, xm, xl = (p.astype(np.float64) for p in (hi, mid, lo))
+    six = wl * xh + wh * xl + wm * xm + wm * xh + wh * xm + wh * xh
+    exact = w.astype(np.float64) * x.astype(np.float64)
+    ok = exact != 0
+    rel = np.abs(six - exact)[ok] / np.abs(exact)[ok]
+    assert np.max(rel) < 2.0 ** -23 and np.sqrt(np.mean(rel ** 2)) < 2.0 ** -25.5, (np.max(rel), np.sqrt(np.mean(rel ** 2)))
+
+
+class WaveX6:
+    def __init__(self, cst, planes):
+        self.cst, self.planes = cst, planes           # planes: the stream as (hi, mid, lo)-split values, one per element
+
+    def layer(self, stage0, n_tiles, kps, frags, bias_off, bias_stride=None):
+        """frags: per k-step [8][64] source values (element j, lane).  k-steps outer, tiles inner, six products."""
+        acc = np.zeros((n_tiles, 32, 32))
+        stride = 16 * n_tiles if bias_stride is None else bias_stride
+        for t in range(n_tiles):
+            for i in range(16):
+                for h in range(2):
+                    acc[t, (i & 3) + 8 * (i >> 2) + 4 * h, :] = self.cst[bias_off + h * stride + 16 * t + i]
+        for ks, f in enumerate(frags):
+            bh, bm, bl = (p.astype(np.float64) for p in split3(f))
+            for t in range(n_tiles):
+                chunk = (stage0 + ks // kps) * X6_STAGE_CHUNKS + ((ks % kps) * n_tiles + t) * 3
+                A = []
+                for plane in range(3):
+                    a = self.planes[(chunk + plane) * X3_CHUNK:(chunk + plane + 1) * X3_CHUNK].reshape(64, 8)
+                    M = np.zeros((32, 16))
+                    for j in range(8):
+                        M[P, 8 * HALF + j] = a[:, j]
+                    A.append(M)
+                B = []
+                for b in (bh, bm, bl):
+                    M = np.zeros((16, 32))
+                    for j in range(8):
+                        M[8 * HALF + j, P] = b[j]
+                    B.append(M)
+                ah, am, al = A
+                Bh, Bm, Bl = B
+                acc[t] += al @ Bh + ah @ Bl + am @ Bm + am @ Bh + ah @ Bm + ah @ Bh
+        return acc
+
+
+def simulate_x6(idx, flat, emb, ins_num):
+    T = (ins_num + 1 + 31) // 32
+    vals = np.where(idx >= 0, flat[np.clip(idx, 0, None)], 0.0).astype(np.float32)
+    cst = vals[:CONST].astype(np.float64)
+    stream = vals[CONST:]
+    hi, mid, lo = split3(stream)
+    plane = (np.arange(stream.size) // X3_CHUNK) % 3              # chunk position modulo 3 (pack_x6_kernel)
+    planes = np.where(plane == 0, hi, np.where(plane == 1, mid, lo)).astype(np.float64)
+    w = WaveX6(cst, planes)
+    pe = np.zeros((32, 64), dtype=np.float32); qe = np.zeros((16, 64), dtype=np.float32)
+    for j in range(32):
+        for h in range(2):
+            s = pos_slot(j, h)
+            if s >= 0:
+                pe[j, HALF == h] = emb[:, s]
+    for j in range(16):
+        for h in range(2):
+            s = pos_slot(j, h, n_freq_slots=12)
+            if s >= 0:
+                qe[j, HALF == h] = emb[:, 63 + s]
+    pe_f = [pe[8 * k:8 * k + 8] for k in range(4)]
+    qe_f = [qe[8 * k:8 * k + 8] for k in range(2)]
+
+    def frags_of(acc, relu):
+        regs = Wave.regs(acc).astype(np.float32)                  # the accumulators are fp32 registers
+        if relu:
+            regs = np.maximum(regs, 0)
+        return [regs[8 * ks:8 * ks + 8] for ks in range(regs.shape[0] // 8)], regs
+
+    act, _ = frags_of(w.layer(X6_STAGE["l0"], 8, 2, pe_f, C_BIAS8), True)
+    for l in range(1, 8):
+        stage0 = X6_STAGE["l1"] + 8 * (l - 1) if l <= 4 else (X6_STAGE["l5"] if l == 5 else X6_STAGE["l6"] + 8 * (l - 6))
+        act, regs = frags_of(w.layer(stage0, 8, 2, act + (pe_f if l == 5 else []), C_BIAS8 + l * 256), True)
+    sig = np.zeros(64)
+    for i in range(128):
+        sig += regs[i].astype(np.float64) * cst[C_DENSW + HALF * 128 + i]
+    sigma = sig[:32] + sig[32:] + cst[C_DENSB]
+    g, _ = frags_of(w.layer(X6_STAGE["rgbf"], 8, 2, act, C_BIAS8 + 8 * 256), False)
+    _, r = frags_of(w.layer(X6_STAGE["rgbh"], 4, 4, g + qe_f, C_BIAS4), True)
+    rgb = np.zeros((3, 32))
+    for c in range(3):
+        v = np.zeros(64)
+        for i in range(64):
+            v += r[i].astype(np.float64) * cst[C_RGBW + c * 128 + HALF * 64 + i]
+        rgb[c] = v[:32] + v[32:] + cst[C_RGBB + c]
+    e, _ = frags_of(w.layer(X6_STAGE["insf"], 8, 2, act, C_BIAS8 + 9 * 256), False)
+    s, _ = frags_of(w.layer(X6_STAGE["insh"], 4, 4, e, C_BIAS4 + 128), True)
+    acc3 = w.layer(X6_STAGE["inso"], T, 8 if T <= 2 else 4, s, C_BIASO, bias_stride=64)
+    ins = acc3.reshape(T * 32, 32)[: ins_num + 1]
+    return np.concatenate([rgb, sigma[None], ins], 0).T
+
+
+@pytest.mark.parametrize("ins_num,seed", [(13, 0), (93, 3), (40, 5)])
+def test_x6_blob_consumed_in_kernel_order_equals_the_field_to_fp32_rounding(ins_num, seed):
+    lib = dm_nerf_amd.load_library()
+    T = (ins_num + 1 + 31) // 32
+    stages = 85 + (1 if T <= 2 else 2)
+    n = lib.dmn_field_pack_index_x6_len(ins_num)
+    assert n == CONST + stages * X6_STAGE_CHUNKS * X3_CHUNK
+    assert lib.dmn_field_blob_x6_bytes(ins_num) == CONST * 4 + stages * X6_STAGE_CHUNKS * 1024
+    idx = np.empty(n, dtype=np.int32)
+    assert lib.dmn_field_pack_index_x6(ins_num, idx.ctypes.data) == 0
+    params = oracle.make_params(ins_num, seed)
+    flat = np.concatenate([params[k].numpy().reshape(-1) for k, _ in oracle.param_specs(ins_num)])
+    x, v = cases.field_rows()
+    emb = torch.cat([oracle.encode(torch.from_numpy(x[:32]), 10), oracle.encode(torch.from_numpy(v[:32]), 4)], -1)
+    with torch.no_grad():
+        want32 = oracle.field(params, emb).numpy()
+        want64 = oracle.field({k: p.double() for k, p in params.items()}, emb.double()).numpy()
+    got = simulate_x6(idx, flat, emb.numpy(), ins_num)
+    assert got.shape == want64.shape
+    # against the fp64 evaluation of the same fp32 parameters: the six-product arithmetic with fp32 layer outputs is
+    # as close to it as the reference's own fp32 evaluation is (both are bounded by the rounding of the activations)
+    err_x6, err_ref = rel_err(got, want64), rel_err(want32, want64)
+    assert err_x6 < 2e-6 and err_x6 < 2.0 * err_ref + 1e-7, (err_x6, err_ref)
+    # every weight appears exactly three times in the stream (hi, mid and lo chunk), every bias / head value once
+    used = np.bincount(idx[CONST:][idx[CONST:] >= 0], minlength=flat.size)
+    assert set(np.unique(used)) <= {0, 3}
+    assert np.bincount(idx[idx >= 0], minlength=flat.size).min() >= 1

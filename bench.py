@@ -7,9 +7,12 @@ HIP hot path, plus the roofline of the dominant kernel and the CPU oracle timed 
 
 One step = one full 800x800 image (640,000 rays) rendered through ``dm_nerf_amd.render_image``
 (ray generation -> per chunk: coarse field, composite, resample+merge, fine field, composite).
-``value`` is measured in the reference's arithmetic (``--precision fp32``: exact fp32 MFMA products); the
-split-precision modes (three 16-bit MFMAs per product) are timed over the same --steps right after it and reported
-beside it (``split_precision_modes``) with their deviation statistics against the CPU oracle.
+``value`` is measured in fp32-grade arithmetic on the bf16 matrix pipe (``--precision bf16x6``: both operands of every
+fp32 product split EXACTLY into three bf16 values, six MFMA products, fp32 accumulation -- no operand bit is dropped;
+``arithmetic_check`` in the output line measures it, the exact-fp32 MFMA kernel and the reference's own fp32 result
+against an fp64 evaluation).  The exact-fp32 MFMA mode (``exact_fp32_mode``) and the two-way split modes (three 16-bit
+MFMAs per product, ``split_precision_modes``) are timed over the same --steps right after it and reported beside it,
+all with their deviation statistics against the CPU oracle.
 Inputs are synthetic (no dataset / checkpoint exists offline): DM-SR style intrinsics, orbit
 poses, PCG64-seeded weights.  With N > 1 (launched by torch.distributed.run,
 one process per GPU) every rank renders its own pose: no data-path collective, weak scaling.
@@ -41,7 +44,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3                   # MI355X_MICROARCH.md: v_mfma_f32
 PEAK_16BIT_MFMA_TFLOPS = 2500.0                # MI355X_MICROARCH.md: bf16 / f16 MFMA, dense (no sparsity)
 # measured with tools/mfma_peak.hip (register-only MFMA loop on all 256 CUs, random operands): the board power limit
 # pulls the engine clock to 1.70 / 1.87 GHz for f16 / bf16; fp32 MFMA holds 2.39 GHz
-SUSTAINED_MFMA_TFLOPS = {"fp16x3": 1738.0, "bf16x3": 1915.0, "fp32": 154.6}
+SUSTAINED_MFMA_TFLOPS = {"fp16x3": 1738.0, "bf16x3": 1915.0, "bf16x6": 1915.0, "fp32": 154.6}
+MFMA_PRODUCTS = {"fp32": 1, "fp16x3": 3, "bf16x3": 3, "bf16x6": 6}      # matrix-pipe products issued per algorithmic product
 PEAK_HBM_GBS = 8000.0                          # MI355X_MICROARCH.md: HBM3E spec
 CPU_CHUNK = 4096                               # the reference's N_test (configs/test/dmsr/study.txt:10)
 
@@ -85,7 +89,8 @@ def synthetic_scene(device, near=4.0, far=15.0):
 def training_leg(nerf, K, pose, device, n_rays: int = 4096, steps: int = 4):
     """BASELINE config 4 on one GPU, outside the timed region: `steps` optimisation steps of `n_rays` random rays of
     the same camera (stochastic path, colour + instance-matching + emptiness losses, Adam), hand-written forward and
-    backward kernels, once with the exact forward and once with the bf16x3 forward."""
+    backward kernels, with the bf16x6 forward (fp32-grade products on the bf16 pipe), the exact-fp32 forward and the bf16x3
+    forward."""
     from dm_nerf_amd import trainer
     pos, view, coarse, fine, args = nerf
     state = [{k: v.clone() for k, v in m.state_dict().items()} for m in (coarse, fine)]
@@ -102,7 +107,7 @@ def training_leg(nerf, K, pose, device, n_rays: int = 4096, steps: int = 4):
               "matching, tests/test_gpu_parity.py) so that the step never waits for the device",
               "backward": "HIP: backward-data + weight-gradient kernels (bf16x3), compositing backward"}
     coarse.train(); fine.train()
-    for prec in ("fp32", "bf16x3"):
+    for prec in ("bf16x6", "fp32", "bf16x3"):
         targs.precision = prec
         opt = trainer.make_optimizer(coarse, fine)
         # losses are read back on the last timed step only (the reference reads them every i_print steps, train_dmsr.py:75)
@@ -178,22 +183,56 @@ def kernel_stats(profile, name):
 
 
 def field_roofline(profile, precision: str, elapsed: float):
-    """Roofline object of the field kernel from the HIP events of one timed region."""
+    """Roofline object of the field kernel from the HIP events of one timed region.
+
+    ``achieved`` is the ALGORITHMIC rate (2 x 693,504 FLOP per sample point / launch time).  ``peak``: the dense MFMA
+    peak of the pipe the kernel runs on (MI355X_MICROARCH.md) divided by the matrix-pipe products the arithmetic issues
+    per algorithmic product -- 1 for the exact-fp32 MFMA, 3 for the two-way splits, 6 for bf16x6 -- i.e. the ceiling of
+    that arithmetic; the same rate against the undivided pipe peak is ``frac_of_pipe_peak_algorithmic``."""
     n_f, t_f, pts_f = kernel_stats(profile, "field_fwd")
     tflops = pts_f * FLOP_PER_POINT / t_f / 1e12
-    x3 = precision != "fp32"
-    peak = PEAK_16BIT_MFMA_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS
-    name = (f"field_fwd_x3_kernel<{precision}> (fused encodings + 8x256 field; every fp32 product = 3 16-bit MFMA "
-            "products on hi/lo splits, fp32 accumulate)" if x3 else
-            "field_fwd_kernel<1> (fused encodings + 8x256 field, exact fp32 MFMA v_mfma_f32_32x32x2_f32)")
-    return {"kernel": name, "bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak,
-            "traffic": None, "mfma_flop_issued_per_algorithmic_flop": 3 if x3 else 1, "launches": n_f,
-            "avg_launch_ms": t_f / max(n_f, 1) * 1e3,
-            "algorithmic_flop_per_launch": pts_f * FLOP_PER_POINT / max(n_f, 1), "time_share_of_step": t_f / elapsed,
-            # nominal peak is at 2.4 GHz; with every CU on 16-bit MFMA the board power limit holds the clock lower:
-            # tools/mfma_peak.hip, profiles/r02a_mfma_shapes.txt
-            "peak_sustained_measured": SUSTAINED_MFMA_TFLOPS[precision],
-            "mfma_issue_frac_of_sustained": (3 if x3 else 1) * tflops / SUSTAINED_MFMA_TFLOPS[precision]}
+    k = MFMA_PRODUCTS[precision]
+    pipe = PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_16BIT_MFMA_TFLOPS
+    name = {"fp32": "field_fwd_kernel<1> (fused encodings + 8x256 field, exact fp32 MFMA v_mfma_f32_32x32x2_f32)",
+            "bf16x6": "field_fwd_x6_kernel<1> (fused encodings + 8x256 field; fp32 operands split exactly into 3 bf16 planes, "
+                      "every fp32 product = 6 v_mfma_f32_32x32x16_bf16 products, fp32 accumulate)"}.get(
+        precision, f"field_fwd_x3_kernel<{precision}> (fused encodings + 8x256 field; every fp32 product = 3 16-bit MFMA "
+                   "products on hi/lo splits, fp32 accumulate)")
+    out = {"kernel": name, "bound": "mfma", "achieved": tflops, "peak": pipe / k, "unit": "TFLOP/s", "frac": tflops * k / pipe,
+           "traffic": None, "mfma_flop_issued_per_algorithmic_flop": k, "pipe_peak": pipe,
+           "frac_of_pipe_peak_algorithmic": tflops / pipe, "launches": n_f, "avg_launch_ms": t_f / max(n_f, 1) * 1e3,
+           "algorithmic_flop_per_launch": pts_f * FLOP_PER_POINT / max(n_f, 1), "time_share_of_step": t_f / elapsed,
+           # nominal peak is at 2.4 GHz; with every CU on 16-bit MFMA the board power limit holds the clock lower:
+           # tools/mfma_peak.hip, profiles/r02a_mfma_shapes.txt
+           "peak_sustained_measured": SUSTAINED_MFMA_TFLOPS[precision],
+           "mfma_issue_frac_of_sustained": k * tflops / SUSTAINED_MFMA_TFLOPS[precision]}
+    if precision != "fp32":     # what the fp32 matrix pipe could do at most for the same algorithmic work
+        out["achieved_over_fp32_mfma_peak"] = tflops / PEAK_F32_MFMA_TFLOPS
+    return out
+
+
+def arithmetic_check(nerf, params, device, n_points: int = 4096):
+    """How far each arithmetic is from the exact result: the fine network on `n_points` encoded sample points of the
+    benchmark scene, every kernel mode and the CPU oracle's fp32 evaluation (the reference's op sequence) against the
+    CPU oracle run in fp64 on the same fp32 parameters.  max |raw - raw64| / max |raw64|."""
+    from oracle import dmnerf_cpu as oracle
+    pos, view, coarse, fine, args = nerf
+    g = torch.Generator().manual_seed(7)
+    x = (torch.rand(n_points, 3, generator=g) * 2 - 1) * 6.0
+    v = torch.nn.functional.normalize(torch.randn(n_points, 3, generator=g), dim=-1)
+    emb = torch.cat([oracle.encode(x, 10), oracle.encode(v, 4)], -1)
+    with torch.no_grad():
+        want = oracle.field({k: p.double() for k, p in params[1].items()}, emb.double())
+        scale = float(want.abs().max())
+        res = {"reference_op_sequence_cpu_fp32": float((oracle.field(params[1], emb).double() - want).abs().max()) / scale}
+        keep = fine.precision
+        for mode in ("fp32", "bf16x6", "fp16x3", "bf16x3"):
+            fine.precision = mode
+            res[mode] = float((fine(emb.to(device)).cpu().double() - want).abs().max()) / scale
+        fine.precision = keep
+    res["what"] = (f"max |raw - raw_fp64| / max |raw_fp64| of the fine network on {n_points} encoded points; raw_fp64 = the "
+                   "CPU oracle in fp64 on the same fp32 parameters")
+    return res
 
 
 def deviation_stats(got: torch.Tensor, want: torch.Tensor):
@@ -258,13 +297,16 @@ def main():
                          "and 65536 saves 2.6 %% of launch ramp and host gaps on the same device (--chunk 4096 for the reference's)")
     ap.add_argument("--cpu-rays", type=int, default=4 * CPU_CHUNK,
                     help="rays of the CPU-baseline sample (0 = skip): 4 chunks of the reference's N_test")
-    ap.add_argument("--precision", default=os.environ.get("DMNERF_PRECISION", "fp32"),
-                    choices=["fp32", "fp16x3", "bf16x3"],
-                    help="arithmetic of the headline `value`: fp32 = the reference's (exact fp32 MFMA products; default); "
-                         "fp16x3 / bf16x3 = three 16-bit MFMAs per product (hi/lo split, fp32 accumulate)")
-    ap.add_argument("--split-modes", default="bf16x3,fp16x3",
-                    help="split-precision modes timed over the same --steps after the headline region and reported beside "
-                         "it with their deviation statistics (N = 1 only; '' = none)")
+    ap.add_argument("--precision", default=os.environ.get("DMNERF_PRECISION", "bf16x6"),
+                    choices=["fp32", "bf16x6", "fp16x3", "bf16x3"],
+                    help="arithmetic of the headline `value`: bf16x6 (default) = fp32 operands split exactly into three bf16 "
+                         "planes, six bf16 MFMA products per fp32 product, fp32 accumulate (all 24 operand bits enter the "
+                         "products); fp32 = exact fp32 MFMA products; fp16x3 / bf16x3 = three 16-bit MFMAs per product on "
+                         "two-way splits (16 / 22 operand bits)")
+    ap.add_argument("--split-modes", default="fp32,bf16x3,fp16x3",
+                    help="the other arithmetics, timed over the same --steps after the headline region and reported beside "
+                         "it with their deviation statistics (N = 1 only; '' = none): fp32 lands in `exact_fp32_mode`, the "
+                         "two-way splits in `split_precision_modes`")
     ap.add_argument("--no-split-legs", "--no-fp32-leg", dest="no_split", action="store_true",
                     help="same as --split-modes '' (profiling scripts: only the headline mode runs)")
     ap.add_argument("--workload", default="study", choices=["study", "replica"],
@@ -343,7 +385,9 @@ def main():
         composite_bytes(1, N_SAMPLES, c_ch) + composite_bytes(1, N_SAMPLES + N_IMPORTANCE, c_ch))
     comp_gbs = comp_bytes / t_c / 1e9 if t_c > 0 else 0.0      # fused modes have no stand-alone compositing launches
     dtype_names = {"fp32": "f32", "fp16x3": "f16x3 (hi/lo split, f32 accumulate)",
-                   "bf16x3": "bf16x3 (hi/lo split, f32 accumulate)"}
+                   "bf16x3": "bf16x3 (hi/lo split, f32 accumulate)",
+                   "bf16x6": "f32 operands as exact 3-way bf16 splits, 6 bf16 MFMA products per product, f32 accumulate "
+                             "(bf16x6)"}
 
     out = {
         "metric": f"rays/sec, {'DM-SR study 800x800' if ns.workload == 'study' else scene}, 64+128 samples (PSNR vs "
@@ -375,9 +419,24 @@ def main():
             out["roofline"]["traffic_source"] = meas["source"]
             out["roofline"]["algorithmic_bytes_per_launch"] = meas["algorithmic_bytes_per_launch"]
 
-    # ---- beside the headline (N = 1 only, outside its timed region): the split-precision modes over the same --steps
+    # ---- beside the headline (N = 1 only, outside its timed region): the other arithmetics over the same --steps
     modes = [m for m in ns.split_modes.split(",") if m and m != ns.precision] if world == 1 and not ns.no_split else []
     images = {ns.precision: rgb}
+    exact_rgb = rgb if ns.precision == "fp32" else None
+    if "fp32" in modes:         # first: the whole-image deviation of every other mode is taken against this render
+        e_m, prof_m, (exact_rgb, _) = timed_images(make_step("fp32"), ns.steps, min(ns.warmup, 2) or 1, barrier)
+        images["fp32"] = exact_rgb
+        out["exact_fp32_mode"] = {"value": ns.steps * H * W / e_m, "unit": "rays/s", "steps": ns.steps,
+                                  "ms_per_step": e_m / ns.steps * 1e3, "dtype": dtype_names["fp32"],
+                                  "roofline": field_roofline(prof_m, "fp32", e_m)}
+        meas = measured_traffic(f"{ns.workload}_chunk{ns.chunk}_field_fp32")
+        if meas is not None and INS_NUM == 13:
+            out["exact_fp32_mode"]["roofline"]["traffic"] = meas["hbm_bytes_per_launch"]
+            out["exact_fp32_mode"]["roofline"]["traffic_source"] = meas["source"]
+        out["headline_over_exact_fp32_mode"] = value / out["exact_fp32_mode"]["value"]
+    if exact_rgb is not None and ns.precision != "fp32":
+        out["whole_image_vs_fp32_mode"] = deviation_stats(rgb.reshape(-1, 3), exact_rgb.reshape(-1, 3))
+    modes = [m for m in modes if m != "fp32"]
     if modes:
         out["split_precision_modes"] = {}
     for mode in modes:
@@ -385,8 +444,8 @@ def main():
         images[mode] = rgb_m
         entry = {"value": ns.steps * H * W / e_m, "unit": "rays/s", "steps": ns.steps, "ms_per_step": e_m / ns.steps * 1e3,
                  "dtype": dtype_names[mode], "roofline": field_roofline(prof_m, mode, e_m)}
-        if ns.precision == "fp32":          # whole image against the exact-arithmetic render of the same pose
-            entry["whole_image_vs_fp32_mode"] = deviation_stats(rgb_m.reshape(-1, 3), rgb.reshape(-1, 3))
+        if exact_rgb is not None:           # whole image against the exact-arithmetic render of the same pose
+            entry["whole_image_vs_fp32_mode"] = deviation_stats(rgb_m.reshape(-1, 3), exact_rgb.reshape(-1, 3))
         # the same image loop with the coarse pass reduced to density (render_image(image_only=True)): bit-identical images,
         # the coarse network's colour / instance heads are not evaluated.  Reported beside, never as `value`.
         only = make_step(mode, image_only=True)
@@ -399,6 +458,8 @@ def main():
         entry["image_only_coarse_pass"] = {"value": H * W / dt_only, "unit": "rays/s", "ms_per_step": dt_only * 1e3,
                                            "identical_image": bool(torch.equal(rgb_only, rgb_m))}
         out["split_precision_modes"][mode] = entry
+    if world == 1 and not ns.no_split:
+        out["arithmetic_check"] = arithmetic_check(nerf, params, device)
 
     if world == 1 and not ns.no_train_leg:
         out["training_step"] = training_leg(nerf, K, poses[0], device)
@@ -419,7 +480,7 @@ def main():
         # (relative = per-ray worst element over max|oracle|; the oracle itself moves by 2e-4 against an fp64 run of the
         # reference behind the sampler)
         dev = {}
-        for mode in [ns.precision] + modes:
+        for mode in [ns.precision] + (["fp32"] if "exact_fp32_mode" in out else []) + modes:
             gpu_out = sample_outputs(nerf, K, pose, mode, ns.cpu_rays, CPU_CHUNK)
             dev[mode] = {k: deviation_stats(gpu_out[k], cpu_out[k]) for k in ("rgb_fine", "depth_fine", "ins_fine")}
         out["deviation_vs_cpu_oracle"] = dev

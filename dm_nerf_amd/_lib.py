@@ -50,6 +50,7 @@ SIGNATURES = {
     "dmn_field_pack_x6": (c_int, [_P, _P, c_int, _P, _P]),
     "dmn_field_fwd_rays_x6": (c_int, [_P, _P, _P, c_long, c_long, c_int, _P, c_int, c_int, _P, _P]),
     "dmn_field_fwd_embedded_x6": (c_int, [_P, c_long, _P, c_int, _P, _P]),
+    "dmn_field_fwd_rays_x6_save": (c_int, [_P, _P, _P, c_long, c_long, c_int, _P, c_int, _P, _P, _P]),
     "dmn_field_composite_x3": (c_int, [_P, _P, _P, c_long, c_long, c_int, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_long,
                                        c_int, _P, _P, _P]),
     "dmn_render_fused": (c_int, [_P, _P, _P, c_long, _P, c_long, c_long, c_int, c_int, _P, _P, c_int, c_int, c_int, _P, _P,

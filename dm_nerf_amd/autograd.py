@@ -30,9 +30,8 @@ class FieldFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rays_o, rays_d, z, model, precision, *params):
-        # "fp16x3" trains in bf16x3: fp16 needs its range flag read back between forward and backward; "bf16x6" (fp32-grade
-        # products on the bf16 pipe) has no saving variant yet and trains with the exact-fp32 forward
-        fwd = "fp32" if precision in ("fp32", "bf16x6") else "bf16x3"
+        # "fp16x3" trains in bf16x3: fp16 needs its range flag read back between forward and backward
+        fwd = precision if precision in ("fp32", "bf16x6") else "bf16x3"
         raw, save = ops.field_rays_save(rays_o, rays_d, z, model.blob(fwd), model.ins_num, fwd)
         ctx.save, ctx.model = save, model
         ctx.meta = [(p.shape, p.numel(), p.requires_grad) for p in params]

@@ -29,8 +29,24 @@ namespace {
 typedef PrecBF16 P6;
 typedef P6::frag frag;
 
-constexpr int kX6LdsBytes = 2 * kX6StageBytes + kConstFloats * 4;      // 113,664 B
+// Stage slots in LDS.  2: the DMA of stage g+1 runs during stage g and is waited for at the barrier that begins stage
+// g+1.  3 (159 KiB of the CU's 160): the DMA of stage g+2 runs during stage g; DMN_X6_XBAR = 0 waits at the barrier of
+// stage g only for the pieces issued a whole stage earlier (counted vmcnt: the 12 pieces of stage g+1 stay in flight),
+// DMN_X6_XBAR = 1 waits for everything there, so that stage g+1 is complete one barrier early and its first fragments
+// can be read ahead of its own barrier.
+#ifndef DMN_X6_SLOTS
+#define DMN_X6_SLOTS 2
+#endif
+#ifndef DMN_X6_XBAR
+#define DMN_X6_XBAR 0
+#endif
+constexpr int kX6Slots = DMN_X6_SLOTS;
+static_assert(kX6Slots == 2 || kX6Slots == 3, "two or three stage slots");
+constexpr bool kX6CrossBarrier = kX6Slots == 3 && DMN_X6_XBAR;
+constexpr int kX6LdsBytes = kX6Slots * kX6StageBytes + kConstFloats * 4;      // 113,664 B (2 slots) / 162,816 B (3)
+static_assert(kX6LdsBytes <= 160 * 1024, "LDS budget of one CU");
 constexpr int kX6PiecesPerWave = kX6StageChunks / 4;                   // 12
+__device__ __forceinline__ int x6_slot(int g) { return kX6Slots == 2 ? (g & 1) : g % 3; }
 
 struct Ctx6 {
   const char* stream;   // weight stream in global memory
@@ -43,7 +59,7 @@ struct Ctx6 {
 // each wave DMA-copies 12 of a stage's 48 chunks
 __device__ __forceinline__ void x6_load_stage(const Ctx6& c, int g) {
   const char* src = c.stream + (long)g * kX6StageBytes + (c.wave_s * kX6PiecesPerWave) * 1024;
-  char* dst = c.lds + (g & 1) * kX6StageBytes + (c.wave_s * kX6PiecesPerWave) * 1024;
+  char* dst = c.lds + x6_slot(g) * kX6StageBytes + (c.wave_s * kX6PiecesPerWave) * 1024;
 #pragma unroll
   for (int q = 0; q < kX6PiecesPerWave; ++q) glds16_u(src + q * 1024, (unsigned)c.lane * 16u, dst + q * 1024);
 }
@@ -51,18 +67,25 @@ __device__ __forceinline__ void x6_load_stage(const Ctx6& c, int g) {
 // Barrier that retires stage g (its DMA has landed, every wave is done with stage g-1); the pieces of stage g+1 are
 // issued by x6_load_piece() behind the MFMA groups of stage g.
 __device__ __forceinline__ void x6_stage_begin(Ctx6& c) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces (inline asm: not in the compiler's count)
+  // this wave's LDS-DMA pieces of the stage (inline asm: not in the compiler's count).  Three slots without the
+  // read-ahead: all but the 12 youngest vector-memory operations -- the pieces of the stage after this one
+  if (kX6Slots == 3 && !kX6CrossBarrier)
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  c.buf = c.lds + (c.g & 1) * kX6StageBytes + c.lane * 16;
+  c.buf = c.lds + x6_slot(c.g) * kX6StageBytes + c.lane * 16;
   ++c.g;
 }
 
-// piece q (0..11) of this wave's share of the NEXT stage (index c.g after x6_stage_begin); past the end of the stream
-// the source clamps to the last stage (the copy lands in the buffer nobody reads any more)
+// piece q (0..11) of this wave's share of the stage kX6Slots - 1 ahead of the running one (the running stage is c.g - 1
+// after x6_stage_begin); past the end of the stream the source clamps to the last stage (the copy lands in a slot nobody
+// reads any more)
 __device__ __forceinline__ void x6_load_piece(const Ctx6& c, int q) {
-  const int g = c.g < c.G ? c.g : c.G - 1;
+  const int gt = c.g + kX6Slots - 2;
+  const int g = gt < c.G ? gt : c.G - 1;
   const char* src = c.stream + (long)g * kX6StageBytes + (c.wave_s * kX6PiecesPerWave + q) * 1024;
-  char* dst = c.lds + (c.g & 1) * kX6StageBytes + (c.wave_s * kX6PiecesPerWave + q) * 1024;
+  char* dst = c.lds + x6_slot(gt) * kX6StageBytes + (c.wave_s * kX6PiecesPerWave + q) * 1024;
   glds16_u(src, (unsigned)c.lane * 16u, dst);
 }
 
@@ -110,15 +133,46 @@ struct SrcH8 {
   }
 };
 
+// ---- training: what a layer's input values leave behind in the save record as they pass by (field_layout.h "Training";
+// the same record the exact-fp32 kernel writes, so the backward kernels do not care which forward ran).  Every
+// activation is read out of its accumulator exactly once per consuming layer, by the operand split: that is where it is
+// stored -- one row store per value, spread over the k-steps, and for post-ReLU layers one sign bit into the layer's
+// mask words (bit b of word w <-> register 32 w + b).
+struct NoSave {
+  __device__ __forceinline__ void operator()(int, float, float) const {}
+};
+template <bool MASK>     // MASK: a post-ReLU layer (its sign bits are collected), else no activation behind the values
+struct SaveRows {
+  float* rows;           // record rows of this layer's values: register i -> rows + i * 64 (lane offset included)
+  unsigned* msk;         // the kernel's four sign-bit words
+  __device__ __forceinline__ void operator()(int i, float x0, float x1) const {
+    record_store(rows + i * 64, x0);
+    record_store(rows + (i + 1) * 64, x1);
+    if (MASK) {          // post-ReLU values are +0 or positive: the sign bit is "bits != 0"
+      const unsigned b0 = __float_as_uint(x0) != 0u ? 1u : 0u, b1 = __float_as_uint(x1) != 0u ? 1u : 0u;
+      msk[i >> 5] |= (b0 << (i & 31)) | (b1 << ((i + 1) & 31));
+    }
+  }
+};
+template <int N>
+__device__ __forceinline__ void flush_mask(float* dst, unsigned* msk) {
+#pragma unroll
+  for (int w = 0; w < N; ++w) {
+    record_store(dst + w * 64, __uint_as_float(msk[w]));
+    msk[w] = 0u;
+  }
+}
+
 // One layer, k-steps outer: out[t] (t < NT) = bias + sum over the NKS k-steps of `src` (ReLU applied first if RELU) and
 // the NKX k-steps of `ext` (encodings, never activated) of the six-term product with the stream's [hi, mid, lo] chunks.
 //   KPS    k-steps per 48-chunk stage (field_layout.h)
 //   KEEP   the activated values of registers 64..127 stay behind in keep[i - 64] (they are in vector registers for the
 //          split anyway; the caller reads them again later and gets their four accumulator tiles back)
 //   LAST   the layer ends the weight stream: no LDS-DMA is issued during its last stage
-template <int NT, int NKS, int NKX, int KPS, bool RELU, bool KEEP, bool LAST, class Src, class Ext>
+//   sav    training: stores the (activated) values of `src` into the save record as they pass (NoSave: inference)
+template <int NT, int NKS, int NKX, int KPS, bool RELU, bool KEEP, bool LAST, class Src, class Ext, class Sav = NoSave>
 __device__ __forceinline__ void layer_x6(Ctx6& c, f32x16* out, const float* bias, const Src& src, const Ext& ext,
-                                         float* keep = nullptr) {
+                                         float* keep = nullptr, const Sav& sav = Sav()) {
   constexpr int NK = NKS + NKX;
   constexpr int GPS = KPS * NT;                 // (k-step, tile) groups per full stage
   static_assert(GPS * 3 <= kX6StageChunks, "a stage holds three chunks per group");
@@ -139,6 +193,7 @@ __device__ __forceinline__ void layer_x6(Ctx6& c, f32x16* out, const float* bias
         x0 = relu_bits(x0);
         x1 = relu_bits(x1);
       }
+      sav(8 * ks + 2 * p, x0, x1);
       if (KEEP && 8 * ks + 2 * p >= 64) {
         keep[8 * ks + 2 * p - 64] = x0;
         keep[8 * ks + 2 * p + 1 - 64] = x1;
@@ -158,29 +213,37 @@ __device__ __forceinline__ void layer_x6(Ctx6& c, f32x16* out, const float* bias
     constexpr int kLastStage = (NK - 1) / KPS;
     const int stage = ks / KPS;
     const int groups = (stage == kLastStage ? NK - stage * KPS : KPS) * NT;     // groups of this stage (last: maybe fewer)
-    const bool dma = !(LAST && stage == kLastStage);
+    // with three slots every stage issues its 12 pieces (clamped past the end): the counted wait relies on it
+    const bool dma = kX6Slots == 3 || !(LAST && stage == kLastStage);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int gi = (ks % KPS) * NT + t;       // group inside its stage
-      const int slot = (ks * NT + t) & 1;
+      const int ar = (ks * NT + t) & 1;
       if (gi == 0) {
         x6_stage_begin(c);
-        ah[slot] = *reinterpret_cast<const frag*>(c.buf);
-        am[slot] = *reinterpret_cast<const frag*>(c.buf + 1024);
-        al[slot] = *reinterpret_cast<const frag*>(c.buf + 2048);
+        if (!(kX6CrossBarrier && stage > 0)) {  // (read ahead of the barrier by the previous stage's last group)
+          ah[ar] = *reinterpret_cast<const frag*>(c.buf);
+          am[ar] = *reinterpret_cast<const frag*>(c.buf + 1024);
+          al[ar] = *reinterpret_cast<const frag*>(c.buf + 2048);
+        }
       }
       if (gi + 1 < groups) {                    // next group's fragments fly under this group's MFMAs
-        ah[slot ^ 1] = *reinterpret_cast<const frag*>(c.buf + (3 * (gi + 1)) * 1024);
-        am[slot ^ 1] = *reinterpret_cast<const frag*>(c.buf + (3 * (gi + 1) + 1) * 1024);
-        al[slot ^ 1] = *reinterpret_cast<const frag*>(c.buf + (3 * (gi + 1) + 2) * 1024);
+        ah[ar ^ 1] = *reinterpret_cast<const frag*>(c.buf + (3 * (gi + 1)) * 1024);
+        am[ar ^ 1] = *reinterpret_cast<const frag*>(c.buf + (3 * (gi + 1) + 1) * 1024);
+        al[ar ^ 1] = *reinterpret_cast<const frag*>(c.buf + (3 * (gi + 1) + 2) * 1024);
+      } else if (kX6CrossBarrier && stage < kLastStage) {      // the next stage landed one barrier ago: read ahead
+        const char* nb = c.lds + x6_slot(c.g) * kX6StageBytes + c.lane * 16;
+        ah[ar ^ 1] = *reinterpret_cast<const frag*>(nb);
+        am[ar ^ 1] = *reinterpret_cast<const frag*>(nb + 1024);
+        al[ar ^ 1] = *reinterpret_cast<const frag*>(nb + 2048);
       }
       __builtin_amdgcn_sched_barrier(0);        // keep the prefetch above this group's MFMAs
-      out[t] = P6::mfma(al[slot], bh, out[t]);  // small terms first
-      out[t] = P6::mfma(ah[slot], bl, out[t]);
-      out[t] = P6::mfma(am[slot], bm, out[t]);
-      out[t] = P6::mfma(am[slot], bh, out[t]);
-      out[t] = P6::mfma(ah[slot], bm, out[t]);
-      out[t] = P6::mfma(ah[slot], bh, out[t]);
+      out[t] = P6::mfma(al[ar], bh, out[t]);    // small terms first
+      out[t] = P6::mfma(ah[ar], bl, out[t]);
+      out[t] = P6::mfma(am[ar], bm, out[t]);
+      out[t] = P6::mfma(am[ar], bh, out[t]);
+      out[t] = P6::mfma(ah[ar], bm, out[t]);
+      out[t] = P6::mfma(ah[ar], bh, out[t]);
       if (dma) {
         if (gi < kX6PiecesPerWave) x6_load_piece(c, gi);
         if (gi + 1 == groups) {                 // a short stage still owes the rest of its pieces
@@ -200,10 +263,11 @@ __device__ __forceinline__ void layer_x6(Ctx6& c, f32x16* out, const float* bias
   }
 }
 
-template <int T>
+// SAVE: also write the save record the backward kernels read (training; field_layout.h "Training")
+template <int T, bool SAVE>
 __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(const FieldArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[kX6LdsBytes];
-  float* const cst = reinterpret_cast<float*>(lds + 2 * kX6StageBytes);
+  float* const cst = reinterpret_cast<float*>(lds + kX6Slots * kX6StageBytes);
   const int tid = threadIdx.x;
   const int lane = tid & 63, p = lane & 31, h = lane >> 5;
   const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -211,14 +275,25 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(const FieldArgs a)
   Ctx6 c{blob + kConstFloats * 4, lds, nullptr, 0, x6_total_stages(T), wave_s, lane};
 
   // const section + stage 0 start streaming while the encodings are computed
-  for (int k = wave_s; k < kConstChunks; k += 4) glds16(blob + k * 1024 + lane * 16, lds + 2 * kX6StageBytes + k * 1024);
+  for (int k = wave_s; k < kConstChunks; k += 4)
+    glds16(blob + k * 1024 + lane * 16, lds + kX6Slots * kX6StageBytes + k * 1024);
   x6_load_stage(c, 0);
+  if (kX6Slots == 3) x6_load_stage(c, 1);
 
   const long m = ((long)blockIdx.x * 4 + wave_s) * 32 + p;
   const bool valid = m < a.M;
   const long mc = valid ? m : a.M - 1;
   float pe[32], qe[16];
   point_encodings(a, mc, h, pe, qe);
+  // training: this wave's save record, lane offset included
+  float* const rec = SAVE ? a.save + ((long)blockIdx.x * 4 + wave_s) * kSaveTileFloats + lane : nullptr;
+  unsigned msk[4] = {0u, 0u, 0u, 0u};
+  if (SAVE) {
+#pragma unroll
+    for (int j = 0; j < 32; ++j) record_store(rec + (kSavePe + j) * 64, pe[j]);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) record_store(rec + (kSaveQe + j) * 64, qe[j]);
+  }
 
   f32x16 accA[8], accB[8];
   float sigma = 0.f;
@@ -229,16 +304,38 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(const FieldArgs a)
 
   // ---- mlps.0: position encoding (4 k-steps) -> A
   layer_x6<8, 4, 0, K8, false, false, false>(c, accA, cst + kConstBias8 + h * 128, s_pe, s_pe);
-  // ---- mlps.1 .. mlps.4 in pairs A -> B -> A (rolled: a layer is ~2500 instructions)
+  // ---- mlps.1 .. mlps.4 in pairs A -> B -> A (rolled: a layer is ~2500 instructions); training: h_l = relu(mlps.(l-1))
+  //      goes into the record while mlps.l consumes it
 #pragma unroll 1
   for (int l = 1; l < 5; l += 2) {
-    layer_x6<8, 16, 0, K8, true, false, false>(c, accB, cst + kConstBias8 + l * 256 + h * 128, s_a, s_pe);
-    layer_x6<8, 16, 0, K8, true, false, false>(c, accA, cst + kConstBias8 + (l + 1) * 256 + h * 128, s_b, s_pe);
+    if constexpr (SAVE) {
+      layer_x6<8, 16, 0, K8, true, false, false>(c, accB, cst + kConstBias8 + l * 256 + h * 128, s_a, s_pe, nullptr,
+                                                 SaveRows<true>{rec + save_h(l) * 64, msk});
+      flush_mask<4>(rec + save_mask(l) * 64, msk);
+      layer_x6<8, 16, 0, K8, true, false, false>(c, accA, cst + kConstBias8 + (l + 1) * 256 + h * 128, s_b, s_pe, nullptr,
+                                                 SaveRows<true>{rec + save_h(l + 1) * 64, msk});
+      flush_mask<4>(rec + save_mask(l + 1) * 64, msk);
+    } else {
+      layer_x6<8, 16, 0, K8, true, false, false>(c, accB, cst + kConstBias8 + l * 256 + h * 128, s_a, s_pe);
+      layer_x6<8, 16, 0, K8, true, false, false>(c, accA, cst + kConstBias8 + (l + 1) * 256 + h * 128, s_b, s_pe);
+    }
   }
   // ---- mlps.5 on cat([h, input_pts]) (skip connection, dm_nerf.py:86-87), mlps.6, mlps.7: A -> B -> A -> B
-  layer_x6<8, 16, 4, K8, true, false, false>(c, accB, cst + kConstBias8 + 5 * 256 + h * 128, s_a, s_pe);
-  layer_x6<8, 16, 0, K8, true, false, false>(c, accA, cst + kConstBias8 + 6 * 256 + h * 128, s_b, s_pe);
-  layer_x6<8, 16, 0, K8, true, false, false>(c, accB, cst + kConstBias8 + 7 * 256 + h * 128, s_a, s_pe);
+  if constexpr (SAVE) {
+    layer_x6<8, 16, 4, K8, true, false, false>(c, accB, cst + kConstBias8 + 5 * 256 + h * 128, s_a, s_pe, nullptr,
+                                               SaveRows<true>{rec + save_h(5) * 64, msk});
+    flush_mask<4>(rec + save_mask(5) * 64, msk);
+    layer_x6<8, 16, 0, K8, true, false, false>(c, accA, cst + kConstBias8 + 6 * 256 + h * 128, s_b, s_pe, nullptr,
+                                               SaveRows<true>{rec + save_h(6) * 64, msk});
+    flush_mask<4>(rec + save_mask(6) * 64, msk);
+    layer_x6<8, 16, 0, K8, true, false, false>(c, accB, cst + kConstBias8 + 7 * 256 + h * 128, s_a, s_pe, nullptr,
+                                               SaveRows<true>{rec + save_h(7) * 64, msk});
+    flush_mask<4>(rec + save_mask(7) * 64, msk);
+  } else {
+    layer_x6<8, 16, 4, K8, true, false, false>(c, accB, cst + kConstBias8 + 5 * 256 + h * 128, s_a, s_pe);
+    layer_x6<8, 16, 0, K8, true, false, false>(c, accA, cst + kConstBias8 + 6 * 256 + h * 128, s_b, s_pe);
+    layer_x6<8, 16, 0, K8, true, false, false>(c, accB, cst + kConstBias8 + 7 * 256 + h * 128, s_a, s_pe);
+  }
 
   // ---- density_linear on h8 = relu(B) (dm_nerf.py:101): 256 -> 1 on the VALU.  (Taken while h8 passes through the
   //      next layer's operand split instead, its 128 weight reads are hoisted together and cost 100 registers there.)
@@ -268,37 +365,53 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(const FieldArgs a)
   //      of the 4-tile layers, so 2 x 128 accumulator registers stay the maximum; ins_feature_linear reads h8 from
   //      both places
   float h8[64];
-  layer_x6<8, 16, 0, K8, true, true, false>(c, accA, cst + kConstBias8 + 8 * 256 + h * 128, s_b, s_pe, h8);
-  // ---- rgb_feature_linears.0 on cat([feature, dirs]) -> 128, ReLU (dm_nerf.py:90-93); rgb_linear on the VALU (:102)
   f32x16 acc2[4];
-  layer_x6<4, 16, 2, K4, false, false, false>(c, acc2, cst + kConstBias4 + h * 64, s_a, s_qe);
   float rgb[3] = {0.f, 0.f, 0.f};
-  {
-    const float* const rw = cst + kConstRgbW + h * 64;
+  const float* const rw = cst + kConstRgbW + h * 64;
+  const SrcH8 s_h8{accB, h8};
+  const SrcTiles s_2{acc2};
+  f32x16 acc3[T];
+  if constexpr (SAVE) {
+    layer_x6<8, 16, 0, K8, true, true, false>(c, accA, cst + kConstBias8 + 8 * 256 + h * 128, s_b, s_pe, h8,
+                                              SaveRows<true>{rec + save_h(8) * 64, msk});
+    flush_mask<4>(rec + save_mask(8) * 64, msk);
+    // ---- rgb_feature_linears.0 on cat([feature, dirs]) -> 128, ReLU (dm_nerf.py:90-93); rgb_linear on the VALU (:102)
+    layer_x6<4, 16, 2, K4, false, false, false>(c, acc2, cst + kConstBias4 + h * 64, s_a, s_qe, nullptr,
+                                                SaveRows<false>{rec + kSaveFeat * 64, msk});
+  } else {
+    layer_x6<8, 16, 0, K8, true, true, false>(c, accA, cst + kConstBias8 + 8 * 256 + h * 128, s_b, s_pe, h8);
+    layer_x6<4, 16, 2, K4, false, false, false>(c, acc2, cst + kConstBias4 + h * 64, s_a, s_qe);
+  }
 #pragma unroll
-    for (int i0 = 0; i0 < 64; i0 += 8) {       // eight values at a time: h8 and the view encoding stay in registers beside it
+  for (int i0 = 0; i0 < 64; i0 += 8) {         // eight values at a time: h8 and the view encoding stay in registers beside it
 #pragma unroll
-      for (int i = i0; i < i0 + 8; ++i) {
-        const float x = relu_bits(acc2[i >> 4][i & 15]);
+    for (int i = i0; i < i0 + 8; i += 2) {
+      const float x0 = relu_bits(acc2[i >> 4][i & 15]), x1 = relu_bits(acc2[(i + 1) >> 4][(i + 1) & 15]);
+      if (SAVE) SaveRows<true>{rec + kSaveR1 * 64, msk}(i, x0, x1);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) rgb[k] = fmaf(x, rw[k * 128 + i], rgb[k]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+      for (int k = 0; k < 3; ++k) rgb[k] = fmaf(x1, rw[k * 128 + i + 1], fmaf(x0, rw[k * 128 + i], rgb[k]));
     }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (SAVE) flush_mask<2>(rec + kSaveMaskR1 * 64, msk);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      rgb[k] += __shfl_xor(rgb[k], 32);
-      rgb[k] += cst[kConstRgbB + k];
-    }
+  for (int k = 0; k < 3; ++k) {
+    rgb[k] += __shfl_xor(rgb[k], 32);
+    rgb[k] += cst[kConstRgbB + k];
   }
   // ---- ins_feature_linear on the same trunk output (h.detach(), dm_nerf.py:95-96), no activation -> A;
   //      ins_feature_linears.0 -> 128, ReLU (:97-99); ins_linear -> ins_num + 1 (:103)
-  const SrcH8 s_h8{accB, h8};
   layer_x6<8, 16, 0, K8, false, false, false>(c, accA, cst + kConstBias8 + 9 * 256 + h * 128, s_h8, s_pe);
-  layer_x6<4, 16, 0, K4, false, false, false>(c, acc2, cst + kConstBias4 + 128 + h * 64, s_a, s_pe);
-  f32x16 acc3[T];
-  const SrcTiles s_2{acc2};
-  layer_x6<T, 8, 0, x6_inso_ksteps_per_stage(T), true, false, true>(c, acc3, cst + kConstBiasO + h * 64, s_2, s_pe);
+  if constexpr (SAVE) {
+    layer_x6<4, 16, 0, K4, false, false, false>(c, acc2, cst + kConstBias4 + 128 + h * 64, s_a, s_pe, nullptr,
+                                                SaveRows<false>{rec + kSaveInsF * 64, msk});
+    layer_x6<T, 8, 0, x6_inso_ksteps_per_stage(T), true, false, true>(c, acc3, cst + kConstBiasO + h * 64, s_2, s_pe, nullptr,
+                                                                     SaveRows<true>{rec + kSaveI1 * 64, msk});
+    flush_mask<2>(rec + kSaveMaskI1 * 64, msk);
+  } else {
+    layer_x6<4, 16, 0, K4, false, false, false>(c, acc2, cst + kConstBias4 + 128 + h * 64, s_a, s_pe);
+    layer_x6<T, 8, 0, x6_inso_ksteps_per_stage(T), true, false, true>(c, acc3, cst + kConstBiasO + h * 64, s_2, s_pe);
+  }
 
   // ---- raw = cat([rgb, density, ins]) (dm_nerf.py:105)
   if (row != nullptr) {
@@ -314,22 +427,28 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(const FieldArgs a)
         if (ch < a.ins_ch) row[4 + ch] = acc3[t][r];
       }
   }
+  if (kX6Slots == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail copies must land before the LDS is released
+}
+
+template <bool SAVE>
+int launch_x6_t(const FieldArgs& a, int ins_num, hipStream_t st) {
+  const long blocks = (a.M + 127) / 128;
+  if (blocks > 0x7fffffffL) return DMN_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)blocks), block(256);
+  switch (ins_tiles(ins_num)) {
+    case 1: hipLaunchKernelGGL((field_fwd_x6_kernel<1, SAVE>), grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL((field_fwd_x6_kernel<2, SAVE>), grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL((field_fwd_x6_kernel<3, SAVE>), grid, block, 0, st, a); break;
+    case 4: hipLaunchKernelGGL((field_fwd_x6_kernel<4, SAVE>), grid, block, 0, st, a); break;
+    default: return DMN_ERR_UNSUPPORTED;
+  }
+  return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
 }
 
 int launch_x6(const FieldArgs& a, int ins_num, hipStream_t st) {
   if (ins_num < 0 || ins_tiles(ins_num) > kMaxInsTiles) return DMN_ERR_UNSUPPORTED;
   if (a.M <= 0) return DMN_OK;
-  const long blocks = (a.M + 127) / 128;
-  if (blocks > 0x7fffffffL) return DMN_ERR_UNSUPPORTED;
-  const dim3 grid((unsigned)blocks), block(256);
-  switch (ins_tiles(ins_num)) {
-    case 1: hipLaunchKernelGGL(field_fwd_x6_kernel<1>, grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL(field_fwd_x6_kernel<2>, grid, block, 0, st, a); break;
-    case 3: hipLaunchKernelGGL(field_fwd_x6_kernel<3>, grid, block, 0, st, a); break;
-    case 4: hipLaunchKernelGGL(field_fwd_x6_kernel<4>, grid, block, 0, st, a); break;
-    default: return DMN_ERR_UNSUPPORTED;
-  }
-  return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
+  return a.save != nullptr ? launch_x6_t<true>(a, ins_num, st) : launch_x6_t<false>(a, ins_num, st);
 }
 
 // blob gather with the exact three-way split; entry i < kConstFloats is an fp32 constant, the rest are bf16 values
@@ -381,5 +500,16 @@ extern "C" int dmn_field_fwd_embedded_x6(const float* embedded, long n_points, c
   if (n_points == 0) return DMN_OK;
   if (!embedded || !blob || !raw) return DMN_ERR_BAD_ARG;
   FieldArgs a{nullptr, nullptr, nullptr, 0, embedded, blob, raw, nullptr, n_points, 1, ins_num + 1, nullptr, 0};
+  return launch_x6(a, ins_num, (hipStream_t)stream);
+}
+
+extern "C" int dmn_field_fwd_rays_x6_save(const float* rays_o, const float* rays_d, const float* z, long z_ray_stride,
+                                          long n_rays, int n_samples, const void* blob, int ins_num, float* raw,
+                                          float* save, void* stream) {
+  if (n_rays < 0 || n_samples <= 0 || ins_num < 0 || z_ray_stride < 0) return DMN_ERR_BAD_ARG;
+  if (n_rays == 0) return DMN_OK;
+  if (!rays_o || !rays_d || !z || !blob || !raw || !save) return DMN_ERR_BAD_ARG;
+  FieldArgs a{rays_o, rays_d, z, z_ray_stride, nullptr, blob, raw, nullptr, n_rays * (long)n_samples, n_samples,
+              ins_num + 1, save, 0};
   return launch_x6(a, ins_num, (hipStream_t)stream);
 }

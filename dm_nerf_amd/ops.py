@@ -282,10 +282,10 @@ def wgrad_index(ins_num: int, device) -> torch.Tensor:
 
 def field_rays_save(rays_o: torch.Tensor, rays_d: torch.Tensor, z: torch.Tensor, blob: torch.Tensor,
                     ins_num: int, precision: str = "fp32") -> Tuple[torch.Tensor, torch.Tensor]:
-    """Field forward that also writes the save record the backward kernels read: exact fp32 ("fp32") or three bf16
-    MFMAs per product ("bf16x3", with the x3 blob of that precision)."""
-    if precision not in ("fp32", "bf16x3"):
-        raise ValueError("the saving forward runs in 'fp32' or 'bf16x3'")
+    """Field forward that also writes the save record the backward kernels read: exact fp32 ("fp32"), fp32-grade products
+    on the bf16 pipe ("bf16x6") or three bf16 MFMAs per product ("bf16x3"), each with the blob of that precision."""
+    if precision not in ("fp32", "bf16x6", "bf16x3"):
+        raise ValueError("the saving forward runs in 'fp32', 'bf16x6' or 'bf16x3'")
     n = rays_o.shape[0]
     rays_o = _dev(rays_o, "rays_o").contiguous()
     rays_d = _dev(rays_d, "rays_d").contiguous()
@@ -297,6 +297,9 @@ def field_rays_save(rays_o: torch.Tensor, rays_d: torch.Tensor, z: torch.Tensor,
         if precision == "fp32":
             check(load().dmn_field_fwd_rays_save(ptr(rays_o), ptr(rays_d), ptr(zz), stride, n, s, ptr(blob), ins_num,
                                                  ptr(raw), ptr(save), current_stream()), "dmn_field_fwd_rays_save")
+        elif precision == "bf16x6":
+            check(load().dmn_field_fwd_rays_x6_save(ptr(rays_o), ptr(rays_d), ptr(zz), stride, n, s, ptr(blob), ins_num,
+                                                    ptr(raw), ptr(save), current_stream()), "dmn_field_fwd_rays_x6_save")
         else:
             check(load().dmn_field_fwd_rays_x3_save(ptr(rays_o), ptr(rays_d), ptr(zz), stride, n, s, ptr(blob),
                                                     ins_num, precision_code(precision), ptr(raw), ptr(save),

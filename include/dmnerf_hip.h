@@ -126,6 +126,10 @@ int dmn_field_fwd_rays_x6(const float* rays_o, const float* rays_d, const float*
                           int n_samples, const void* blob, int ins_num, int sigma_only, float* raw, void* stream);
 int dmn_field_fwd_embedded_x6(const float* embedded, long n_points, const void* blob, int ins_num, float* raw,
                               void* stream);
+/* The same with the save record of dmn_field_fwd_rays_save (training: the backward kernels read it; the record does not
+ * depend on which forward wrote it).                                                                                */
+int dmn_field_fwd_rays_x6_save(const float* rays_o, const float* rays_d, const float* z, long z_ray_stride, long n_rays,
+                               int n_samples, const void* blob, int ins_num, float* raw, float* save, void* stream);
 
 /* ---- field evaluation + compositing (+ resampling) fused: `raw` never reaches memory ----------------------
  * For the image loop (networks/tester.py:62-76 keeps rgb_fine / ins_fine only).  One launch evaluates the field of

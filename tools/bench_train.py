@@ -27,7 +27,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--gpus", type=int, default=1)
 ap.add_argument("--rays", type=int, default=4096, help="rays per optimisation step over all ranks (N_rand)")
 ap.add_argument("--steps", type=int, default=5)
-ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "fp16x3"])
+ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x6", "bf16x3", "fp16x3"])
 ap.add_argument("--instance", action="store_true", help="add the instance-matching loss on random labels")
 ap.add_argument("--assign", default="device", choices=["host", "device"],
                 help="Hungarian step of the instance loss: scipy on the host (one wait for the device per step) or the kernel")

@@ -6,7 +6,9 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dm_nerf_amd as dm
 from dm_nerf_amd import ops, synthetic
 

@@ -75,7 +75,7 @@ class DM_NeRF(nn.Module):
         self.density_linear = nn.Linear(W, 1)
         self.ins_linear = nn.Linear(W // 2, ins_num + 1)
         self.rgb_linear = nn.Linear(W // 2, 3)
-        self.precision = "fp32"          # arithmetic of forward(); the render path passes its own
+        self.precision = ops.DEFAULT_PRECISION      # arithmetic of forward(); the render path passes its own
         self._blobs = {}                 # precision -> (key, blob)
         self._indices = {}               # (flavour, device) -> gather table
         self._flat = None                # (key, parameters as one flat vector) of the last blob packed

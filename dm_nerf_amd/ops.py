@@ -16,7 +16,13 @@ MAX_INS_CHANNELS = 128
 
 # arithmetic of the field kernel (include/dmnerf_hip.h DMN_PREC_*)
 PRECISIONS = {"fp32": 0, "fp16x3": 1, "bf16x3": 2, "bf16x6": 3}
-X3_PRECISIONS = ("fp16x3", "bf16x3")        # two-way split kernels (16 operand bits); "bf16x6" carries all 24
+X3_PRECISIONS = ("fp16x3", "bf16x3")        # two-way split kernels (22 / 16 operand bits); "bf16x6" carries all 24
+# What dm_nerf(), the image loop and DM_NeRF.forward() run when the caller does not say (args.precision / model.precision):
+# fp32-grade products on the bf16 matrix pipe -- every fp32 operand enters the products with all of its 24 significand
+# bits (exact three-way bf16 splits, six MFMA products, fp32 accumulation): as close to an fp64 evaluation as the exact
+# fp32-MFMA kernel and the reference's own fp32 result are (tests/test_gpu_parity.py), at 1.8x the exact kernel's rays/s.
+# "fp32" selects the exact-fp32 MFMA kernel (a k-ordered fma chain), "fp16x3" / "bf16x3" the narrower two-way splits.
+DEFAULT_PRECISION = "bf16x6"
 STATUS_FP16_RANGE = 1
 _status = {}
 

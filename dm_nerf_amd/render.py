@@ -37,16 +37,17 @@ def dm_nerf(rays, position_embedder, view_embedder, model_coarse, model_fine, z_
     ``args`` supplies ``perturb``, ``N_importance``, ``is_train`` and ``N_ins`` like the reference's
     namespace; optional ``args.t_rand`` / ``args.u`` replace the two ``torch.rand`` draws of the
     stochastic path (render.py:46, helpers.py:135) so that it can be checked against recorded draws.
-    ``args.precision`` selects the field kernel's arithmetic: "fp32" (default: exact fp32 MFMA), "fp16x3"
-    or "bf16x3" (three 16-bit MFMAs per product).  With "fp16x3" the caller must look at
-    ``ops.take_status`` afterwards (``render_image`` does): activations beyond the fp16 range are flagged,
-    never silently wrong."""
+    ``args.precision`` selects the field kernel's arithmetic: "bf16x6" (``ops.DEFAULT_PRECISION``: fp32 operands split
+    exactly into three bf16 values, six bf16 MFMA products per fp32 product, fp32 accumulation -- fp32-grade), "fp32"
+    (exact fp32 MFMA products), "fp16x3" or "bf16x3" (three 16-bit MFMAs per product on two-way splits: 22 / 16 operand
+    bits).  With "fp16x3" the caller must look at ``ops.take_status`` afterwards (``render_image`` does): activations
+    beyond the fp16 range are flagged, never silently wrong."""
     _check_embedders(position_embedder, view_embedder)
     if not (isinstance(model_coarse, DM_NeRF) and isinstance(model_fine, DM_NeRF)):
         raise TypeError("model_coarse / model_fine must be dm_nerf_amd.DM_NeRF modules")
     train = needs_grad(model_coarse, model_fine)
     rays_o, rays_d = rays
-    precision = getattr(args, "precision", None) or "fp32"
+    precision = getattr(args, "precision", None) or ops.DEFAULT_PRECISION
     n_importance = int(args.N_importance)
     perturb = float(args.perturb)
 

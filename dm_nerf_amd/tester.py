@@ -27,13 +27,14 @@ def render_image(position_embedder, view_embedder, model_coarse, model_fine, c2w
     (tester.py:70-76 keeps ``rgb_fine`` and ``ins_fine``); the returned images are bit-identical."""
     H, W, K = hwk
     chunk = int(chunk or args.N_test)
-    # Reference arithmetic (exact fp32 products) unless the caller opts in: args.precision = "fp16x3" | "bf16x3" selects
-    # the split-precision field kernel (three 16-bit MFMAs per product, fp32 accumulate: 1e-6 / 7e-6 on raw against the
-    # reference, ~3x the rays/s).  Same default as dm_nerf().
-    precision = getattr(args, "precision", None) or "fp32"
+    # fp32-grade arithmetic unless the caller says otherwise (ops.DEFAULT_PRECISION = "bf16x6": all 24 bits of every fp32
+    # operand enter the products; same default as dm_nerf()).  args.precision = "fp32" selects the exact-fp32 MFMA kernel,
+    # "fp16x3" | "bf16x3" the two-way split kernels (three 16-bit MFMAs per product: 1e-6 / 7e-6 on raw against the
+    # reference, 1.7x the default's rays/s) -- narrower arithmetic is never chosen silently.
+    precision = getattr(args, "precision", None) or ops.DEFAULT_PRECISION
     if image_only and precision == "fp32":
-        raise ValueError("image_only (density-only coarse pass) is a mode of the split-precision kernels: set "
-                         "args.precision to 'fp16x3' or 'bf16x3'")
+        raise ValueError("image_only (density-only coarse pass) is a mode of the bf16 / fp16 matrix-pipe kernels: set "
+                         "args.precision to 'bf16x6', 'fp16x3' or 'bf16x3'")
     if getattr(args, "precision", None) != precision or image_only:
         args = SimpleNamespace(**{**vars(args), "precision": precision, "coarse_heads": not image_only})
     if precision == "fp16x3":

@@ -1494,7 +1494,7 @@ def test_manipulator_two_pass_rerender_matches_the_reference(golden):
 
 
 # ---- the one-call C entry for a chunk ----------------------------------------------------------------------
-@pytest.mark.parametrize("precision,stochastic", [("fp32", False), ("bf16x3", True)])
+@pytest.mark.parametrize("precision,stochastic", [("fp32", False), ("bf16x3", True), ("bf16x6", True), ("bf16x6", False)])
 def test_render_rays_entry_point_equals_the_chained_calls(precision, stochastic):
     """dmn_render_rays (coarse -> composite -> resample -> fine -> composite in one C call) against dm_nerf(), which
     chains the same kernels from Python: bit-identical, and the workspace holds raw_* / z_vals_fine."""

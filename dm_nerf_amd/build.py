@@ -19,7 +19,7 @@ LIB = os.path.join(CSRC, "libdmnerf_hip.so")
 OBJ = os.path.join(CSRC, "build")
 SOURCES = ["field_fwd.hip", "field_fwd_x3.hip", "field_fwd_x6.hip", "field_fused_x3.hip", "field_bwd.hip", "field_bwd_x3.hip", "render_ops.hip",
            "composite_bwd.hip", "penalizer.hip", "ins_stats.hip", "exchange.hip", "field_pack.cpp", "render_chain.cpp"]
-HEADERS = ["field_layout.h", "field_common.h", "field_stream.h", "field_x3.h", "field_x3_net.h", "composite_common.h", "trig.h",
+HEADERS = ["field_layout.h", "field_common.h", "field_stream.h", "field_x3.h", "field_x3_net.h", "field_x6.h", "composite_common.h", "trig.h",
            os.path.join("..", "..", "include", "dmnerf_hip.h")]
 # -ffp-contract=off: the path reproduces separately rounded fp32 multiplies and adds of the
 # reference (e.g. pts = o + d*z feeds a 2^9 frequency band); fused multiply-adds are explicit.

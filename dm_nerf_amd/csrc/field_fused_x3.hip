@@ -5,7 +5,9 @@
 //   fine pass:    field(o + d z_fine)   -> composite -> rgb_map, depth_map, ins_map                   (render.py:71-86)
 //
 // A workgroup owns TWO rays.  It walks them in passes of 64 samples per ray: the 4 waves evaluate the network on
-// 2 x 64 = 128 points exactly as field_fwd_x3_kernel does (same weight stream, same x3_network(), so the same bits),
+// 2 x 64 = 128 points exactly as the stand-alone field kernel of the same arithmetic does -- field_fwd_x3_kernel /
+// x3_network() for the two-way splits, field_fwd_x6_kernel / x6_network() for bf16x6: same weight stream, same device
+// function, so the same bits --,
 // park the 128 raw rows in LDS -- in the weight stage buffers, which are idle between the last layer of a pass and
 // the first stage of the next -- and the ray's two waves composite its 64-sample slab with composite_slab(), the
 // function the stand-alone compositing kernels run (half of the channels each).  Transmittance and channel sums are
@@ -22,6 +24,7 @@
 #include "field_common.h"
 #include "field_x3.h"
 #include "field_x3_net.h"
+#include "field_x6.h"
 
 using namespace dmn;
 
@@ -34,7 +37,47 @@ using namespace dmn;
 namespace {
 
 constexpr int kFusedExtraBytes = 16 * 1024;     // weights of the ray + resampling scratch, outside the stage buffers
-static_assert(kLdsBytes + kFusedExtraBytes <= 160 * 1024, "LDS budget of one CU");
+
+// Which field arithmetic a fused kernel runs: its weight-stream context, its LDS geometry ([stage slots | constants],
+// the slots double as the parking area of the raw rows between two passes) and the network on a wave's 32 points.
+template <class P>
+struct NetX3 {
+  typedef Ctx ctx_t;
+  static constexpr int kLds = kLdsBytes, kStageArea = 2 * kX3StageBytes;
+  static constexpr bool kCheckRange = P::kCheckRange;
+  template <int T>
+  static __device__ __forceinline__ ctx_t begin(const char* blob, char* lds, int wave_s, int lane) {
+    Ctx c{blob + kConstFloats * 4, lds, nullptr, 0, kX3Stages, wave_s, lane};
+    load_stage(c, 0);
+    return c;
+  }
+  template <int T>
+  static __device__ __forceinline__ void run(ctx_t& c, const FieldArgs& f, long mc, int h, const float* cst, float& amax,
+                                             float& sigma, float (&rgb)[3], float (&insv)[16 * T]) {
+    typename P::frag pe_h[4], pe_l[4], qe_h[2], qe_l[2];
+    x3_point_fragments<P>(f, mc, h, amax, pe_h, pe_l, qe_h, qe_l);
+    x3_network<P, T>(c, cst, pe_h, pe_l, qe_h, qe_l, h, f.sigma_only != 0, amax, sigma, rgb, insv);
+  }
+};
+struct NetX6 {
+  typedef Ctx6 ctx_t;
+  static constexpr int kLds = kX6LdsBytes, kStageArea = kX6Slots * kX6StageBytes;
+  static constexpr bool kCheckRange = false;
+  template <int T>
+  static __device__ __forceinline__ ctx_t begin(const char* blob, char* lds, int wave_s, int lane) {
+    Ctx6 c{blob + kConstFloats * 4, lds, nullptr, 0, x6_total_stages(T), wave_s, lane};
+    x6_load_stage(c, 0);
+    if (kX6Slots == 3) x6_load_stage(c, 1);
+    return c;
+  }
+  template <int T>
+  static __device__ __forceinline__ void run(ctx_t& c, const FieldArgs& f, long mc, int h, const float* cst, float& amax,
+                                             float& sigma, float (&rgb)[3], float (&insv)[16 * T]) {
+    float pe[32], qe[16];
+    point_encodings(f, mc, h, pe, qe);
+    x6_network<T, false>(c, cst, pe, qe, h, f.sigma_only != 0, nullptr, sigma, rgb, insv);
+  }
+};
 
 struct FusedArgs {
   FieldArgs f;           // rays, depths, blob, status, S, ins_ch, sigma_only (raw / emb / save unused)
@@ -49,17 +92,17 @@ struct FusedArgs {
   float* z_fine;         // [N, S + n_new]
 };
 
-template <class P, int T>
+template <class Net, int T>
 __global__ __launch_bounds__(256, 1) void field_fused_x3_kernel(const FusedArgs a) {
-  typedef typename P::frag frag;
-  __shared__ __attribute__((aligned(16))) char lds[kLdsBytes + kFusedExtraBytes];
-  float* const cst = reinterpret_cast<float*>(lds + 2 * kX3StageBytes);
+  static_assert(Net::kLds + kFusedExtraBytes <= 160 * 1024, "LDS budget of one CU");
+  __shared__ __attribute__((aligned(16))) char lds[Net::kLds + kFusedExtraBytes];
+  float* const cst = reinterpret_cast<float*>(lds + Net::kStageArea);
   const int tid = threadIdx.x;
   const int lane = tid & 63, p = lane & 31, h = lane >> 5;
   const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pair = wave_s >> 1, part = wave_s & 1;        // ray of the workgroup, half of its 64-sample slab
   const char* const blob = static_cast<const char*>(a.f.blob);
-  for (int k = wave_s; k < kConstChunks; k += 4) glds16(blob + k * 1024 + lane * 16, lds + 2 * kX3StageBytes + k * 1024);
+  for (int k = wave_s; k < kConstChunks; k += 4) glds16(blob + k * 1024 + lane * 16, lds + Net::kStageArea + k * 1024);
 
   const int S = a.f.S, C = 4 + a.f.ins_ch;
   const long ray = (long)blockIdx.x * 2 + pair;
@@ -68,7 +111,7 @@ __global__ __launch_bounds__(256, 1) void field_fused_x3_kernel(const FusedArgs 
   const float norm = ray_norm(a.f.rays_d + 3 * rayc);
   const float* const zr = a.f.z + rayc * a.f.z_stride;
   float* const slab = reinterpret_cast<float*>(lds) + (long)pair * 64 * C;            // in the stage buffers
-  float* const extra = reinterpret_cast<float*>(lds + kLdsBytes) + (long)pair * (kFusedExtraBytes / 8);
+  float* const extra = reinterpret_cast<float*>(lds + Net::kLds) + (long)pair * (kFusedExtraBytes / 8);
   float* const wts = extra;                                                            // [S] weights of this ray
   const bool maps = a.rgb != nullptr || a.depth != nullptr || a.ins != nullptr;
 
@@ -81,18 +124,13 @@ __global__ __launch_bounds__(256, 1) void field_fused_x3_kernel(const FusedArgs 
   RayComposite st;
   float amax = 0.f;
   for (int s0 = 0; s0 < S; s0 += 64) {
-    Ctx c{blob + kConstFloats * 4, lds, nullptr, 0, kX3Stages, wave_s, lane};
-    load_stage(c, 0);
+    typename Net::ctx_t c = Net::template begin<T>(blob, lds, wave_s, lane);
     // depths of the compositing lane's sample and of the next one: asked for now, used after the network
     const float zc = zr[s0 + lane];
     const float zn = s0 + lane + 1 < S ? zr[s0 + lane + 1] : 0.f;
     const long mc = rayc * S + s0 + 32 * part + p;
     float sigma, rgb[3], insv[16 * T];
-    {
-      frag pe_h[4], pe_l[4], qe_h[2], qe_l[2];
-      x3_point_fragments<P>(a.f, mc, h, amax, pe_h, pe_l, qe_h, qe_l);
-      x3_network<P, T>(c, cst, pe_h, pe_l, qe_h, qe_l, h, a.f.sigma_only != 0, amax, sigma, rgb, insv);
-    }
+    Net::template run<T>(c, a.f, mc, h, cst, amax, sigma, rgb, insv);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA has landed
 #if DMN_FUSED_ABL == 2
     if (sigma + rgb[0] + insv[0] == 12345.f) slab[lane] = sigma;      // keep the network alive
@@ -122,7 +160,7 @@ __global__ __launch_bounds__(256, 1) void field_fused_x3_kernel(const FusedArgs 
     }
     __syncthreads();                                    // slab consumed: the next pass may stream weights over it
   }
-  if (P::kCheckRange && a.f.status != nullptr && !(amax < 60000.f)) atomicOr(a.f.status, DMN_STATUS_FP16_RANGE);
+  if (Net::kCheckRange && a.f.status != nullptr && !(amax < 60000.f)) atomicOr(a.f.status, DMN_STATUS_FP16_RANGE);
   if (!ray_ok) return;
   if (composites && maps) composite_outputs(st, ray, C, 0, lane, a.rgb, a.depth, a.ins, c_lo, c_hi);
   if (part == 0 && a.z_fine != nullptr) {
@@ -137,6 +175,7 @@ __global__ __launch_bounds__(256, 1) void field_fused_x3_kernel(const FusedArgs 
 
 template <class P>
 int launch_fused(const FusedArgs& a, int ins_num, hipStream_t st) {
+  if (2L * 64 * (5 + ins_num) * 4 > P::kStageArea) return DMN_ERR_UNSUPPORTED;      // the two rays' raw rows of a pass
   const long blocks = (a.n_rays + 1) / 2;
   if (blocks > 0x7fffffffL) return DMN_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)blocks), block(256);
@@ -165,7 +204,6 @@ extern "C" int dmn_field_composite_x3(const float* rays_o, const float* rays_d, 
   if (ins_tiles(ins_num) > kMaxInsTiles) return DMN_ERR_UNSUPPORTED;
   if (z_fine != nullptr && (n_samples < 3 || (4L * n_samples + n_new) * 4 > kFusedExtraBytes / 2))
     return DMN_ERR_UNSUPPORTED;
-  if (2L * 64 * (5 + ins_num) * 4 > 2L * kX3StageBytes) return DMN_ERR_UNSUPPORTED;
   FusedArgs a{};
   a.f = FieldArgs{rays_o, rays_d, z, z_ray_stride, nullptr, blob, nullptr, status, n_rays * (long)n_samples, n_samples,
                   ins_num + 1, nullptr, sigma_only ? 1 : 0};
@@ -173,8 +211,9 @@ extern "C" int dmn_field_composite_x3(const float* rays_o, const float* rays_d, 
   a.rgb = rgb; a.depth = depth; a.ins = ins; a.weights = weights;
   a.u = u; a.u_stride = u_ray_stride; a.n_new = n_new; a.z_fine = z_fine;
   hipStream_t st = (hipStream_t)stream;
-  if (precision == DMN_PREC_FP16X3) return launch_fused<PrecF16>(a, ins_num, st);
-  if (precision == DMN_PREC_BF16X3) return launch_fused<PrecBF16>(a, ins_num, st);
+  if (precision == DMN_PREC_FP16X3) return launch_fused<NetX3<PrecF16>>(a, ins_num, st);
+  if (precision == DMN_PREC_BF16X3) return launch_fused<NetX3<PrecBF16>>(a, ins_num, st);
+  if (precision == DMN_PREC_BF16X6) return launch_fused<NetX6>(a, ins_num, st);      // blob: the x6 blob
   return DMN_ERR_BAD_ARG;
 }
 

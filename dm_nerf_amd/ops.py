@@ -404,10 +404,10 @@ FUSED_SCRATCH_FLOATS = 2048  # = kFusedExtraBytes / 2 / 4 of csrc/field_fused_x3
 
 
 def fused_supported(n_samples: int, n_importance: int, ins_num: int, precision: str) -> bool:
-    """Whether ``render_fused`` covers this configuration: split-precision kernels, 64-sample passes, and the coarse
+    """Whether ``render_fused`` covers this configuration: bf16 / fp16 matrix-pipe kernels, 64-sample passes, and the coarse
     launch's resampling scratch -- (4 * n_samples + n_importance) floats per ray -- inside its 8 KB of LDS (the same
     bound ``dmn_field_composite_x3`` checks; beyond it the image loop takes the chained kernels)."""
-    return (precision in X3_PRECISIONS and n_samples % 64 == 0 and (n_samples + n_importance) % 64 == 0
+    return (precision in X3_PRECISIONS + ("bf16x6",) and n_samples % 64 == 0 and (n_samples + n_importance) % 64 == 0
             and n_samples >= 64 and 0 <= n_importance <= 1024 and 4 * n_samples + n_importance <= FUSED_SCRATCH_FLOATS
             and ins_num + 1 <= MAX_INS_CHANNELS)
 

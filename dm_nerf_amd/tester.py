@@ -21,8 +21,9 @@ def render_image(position_embedder, view_embedder, model_coarse, model_fine, c2w
     """Render one pose.  ``chunk`` defaults to ``args.N_test`` (tester.py:62); the reference's
     O(chunks^2) ``torch.cat`` growth (tester.py:72-76) is replaced by writes into preallocated
     images.  ``ray_range=(a, b)`` renders only flat rays ``[a, b)`` (multi-GPU sharding of one
-    image) and returns flat ``[b-a, .]`` tensors.  With a split precision (``args.precision``) the chunks run through the
-    fused field + compositing kernels (``ops.render_fused``).  ``image_only`` (split precisions): the coarse network evaluates
+    image) and returns flat ``[b-a, .]`` tensors.  With rows wider than 32 channels the chunks of every arithmetic but the
+    exact-fp32 one run through the fused field + compositing kernels (``ops.render_fused``).  ``image_only`` (the same
+    arithmetics): the coarse network evaluates
     its density only -- the colour / instance heads of the coarse pass feed nothing this loop returns
     (tester.py:70-76 keeps ``rgb_fine`` and ``ins_fine``); the returned images are bit-identical."""
     H, W, K = hwk
@@ -46,15 +47,17 @@ def render_image(position_embedder, view_embedder, model_coarse, model_fine, c2w
     n_total = hi - lo
     rgb = torch.empty(n_total, 3, dtype=torch.float32, device=rays_o.device)
     ins = torch.empty(n_total, model_fine.ins_num, dtype=torch.float32, device=rays_o.device)
-    # Split-precision modes can run field evaluation, compositing and resampling fused (ops.render_fused: two launches
-    # per chunk, `raw` never reaches memory, results bit-identical to dm_nerf()'s chain -- tests/test_gpu_parity.py).
-    # Measured on one MI355X (bf16x3, 65536-ray chunks): +2.0 % rays/s with Replica's 98-channel rows, where the chain
-    # moves 100 KB of raw per ray through HBM with scattered row stores; -1 % with DM-SR's 18 channels, where compositing
-    # is 0.6 % of a step and a lone wave per ray composites while its CU idles.  So: on by default for rows wider than
-    # the lane-per-sample compositing form (ops.FUSED_MIN_CHANNELS); args.fused = True / False overrides.
+    # Every arithmetic but the exact-fp32 one can run field evaluation, compositing and resampling fused (ops.render_fused:
+    # two launches per chunk, `raw` never reaches memory, results bit-identical to dm_nerf()'s chain --
+    # tests/test_gpu_parity.py).  Measured on one MI355X (65536-ray chunks), two-way splits (bf16x3): +5.6 % rays/s with
+    # Replica's 98-channel rows, where the chain moves 100 KB of raw per ray through HBM with scattered row stores; -1 %
+    # with DM-SR's 18 channels, where compositing is 0.6 % of a step and a lone wave per ray composites while its CU idles.
+    # bf16x6 (twice the matrix work per point, so half the relative gain against the same idle waves): -0.9 % at 98
+    # channels (650 k against 656 k rays/s).  So: on by default for the two-way splits with rows wider than the
+    # lane-per-sample compositing form (ops.FUSED_MIN_CHANNELS); args.fused = True / False overrides.
     want = getattr(args, "fused", None)
     if want is None:
-        want = model_fine.ins_num + 5 > ops.FUSED_MIN_CHANNELS
+        want = precision in ops.X3_PRECISIONS and model_fine.ins_num + 5 > ops.FUSED_MIN_CHANNELS
     fused = (bool(want) and float(args.perturb) == 0.0
              and ops.fused_supported(int(args.N_samples), int(args.N_importance), model_fine.ins_num, precision))
     with torch.no_grad():

@@ -133,7 +133,7 @@ int dmn_field_fwd_rays_x6_save(const float* rays_o, const float* rays_d, const f
 
 /* ---- field evaluation + compositing (+ resampling) fused: `raw` never reaches memory ----------------------
  * For the image loop (networks/tester.py:62-76 keeps rgb_fine / ins_fine only).  One launch evaluates the field of
- * `precision` (split-precision kernels: DMN_PREC_FP16X3 / DMN_PREC_BF16X3) on o + d*z, composites every ray as
+ * `precision` (DMN_PREC_FP16X3 / DMN_PREC_BF16X3 with the x3 blob, DMN_PREC_BF16X6 with the x6 blob) on o + d*z, composites every ray as
  * dmn_composite_fwd does (render_train, networks/render.py:6-28; keep_last = 0) and, when z_fine != NULL, runs the
  * resampling of dmn_resample_merge on the ray's weights (networks/render.py:66-70: draws u as there, NULL = det).
  * rgb [N,3], depth [N], ins [N,ins_num], weights [N,S] may each be NULL.  sigma_only: the network stops behind its

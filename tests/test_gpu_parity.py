@@ -680,6 +680,14 @@ def test_fp16_range_flag_and_exact_fallback():
     args.precision = "bf16x3"                                   # bf16 has fp32's range: no flag, close result
     rgb_b, _ = dm.render_image(pos, view, coarse, fine, cases.study_c2w(), hwk, args)
     assert np.isfinite(H(rgb_b)).all()
+    # bf16x6 splits every fp32 value exactly whatever its magnitude: the coarse field on activations of ~1e5 stays at
+    # the exact kernel's distance from the oracle
+    o, d, _, _ = cases.path_rays(24, seed=3)
+    z = dm.z_val_sample(24, cases.NEAR, cases.FAR, 64)
+    with torch.no_grad():
+        want = oracle.field_on_rays(big, torch.from_numpy(o), torch.from_numpy(d), z.cpu().contiguous()).numpy()
+    err = {p: rel_err(H(ops.field_rays(G(o), G(d), z, coarse.blob(p), 13, p)), want) for p in ("fp32", "bf16x6")}
+    assert err["bf16x6"] < 2.0 * err["fp32"] + 1e-7 and err["bf16x6"] < 1e-5, err
 
 
 # ---- training: gradients through the HIP path (row T / K11) --------------------------------------------
@@ -1308,7 +1316,7 @@ def test_image_only_coarse_pass_gives_bit_identical_images(precision):
 
 
 # ---- field + compositing (+ resampling) fused in one kernel: the image loop's path in the split precisions ---------
-@pytest.mark.parametrize("precision", ["bf16x3", "fp16x3"])
+@pytest.mark.parametrize("precision", ["bf16x3", "fp16x3", "bf16x6"])
 @pytest.mark.parametrize("ins_num,n_rays,n_samples", [(13, 37, 64), (13, 6, 192), (93, 9, 64), (93, 4, 192), (127, 3, 128),
                                                       (0, 2, 64)])
 def test_fused_field_composite_is_bit_identical_to_the_chain(precision, ins_num, n_rays, n_samples):
@@ -1351,7 +1359,7 @@ def test_fused_field_composite_is_bit_identical_to_the_chain(precision, ins_num,
         ops.field_composite(o, d, z[:, :50].contiguous(), blob, ins_num, precision)
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "fp16x3"])
+@pytest.mark.parametrize("precision", ["bf16x3", "fp16x3", "bf16x6"])
 def test_image_loop_fused_path_equals_the_chained_path(precision):
     """render_image in a split precision runs ops.render_fused; args.fused = False runs dm_nerf()'s chain: same bits,
     ragged last chunk with an odd ray count, with and without the density-only coarse pass, Replica-wide rows."""

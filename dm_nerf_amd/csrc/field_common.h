@@ -66,6 +66,18 @@ __device__ __forceinline__ void glds16_u(const char* base_uniform, unsigned lane
 #endif
 }
 
+// The same for a piece at a compile-time byte offset OFF inside a block whose source (global, wave-uniform) and
+// destination (LDS, wave-uniform) bases are given: the offset is added to both INSIDE the statement (scalar adds into a
+// fixed SGPR pair and M0), so that per piece the compiler sees no address arithmetic at all -- given one expression per
+// piece it computes hundreds of them at the top of a basic block and parks them in vector-register lanes.
+template <int OFF>
+__device__ __forceinline__ void glds16_at(const char* src_base_uniform, unsigned lane_bytes, unsigned lds_base_uniform) {
+  const unsigned long long a = (unsigned long long)src_base_uniform;
+  asm volatile("s_add_i32 m0, %2, %4\n\ts_add_u32 s98, %0, %4\n\ts_addc_u32 s99, %1, 0\n\tglobal_load_lds_dwordx4 %3, s[98:99]"
+               : : "s"((unsigned)a), "s"((unsigned)(a >> 32)), "s"(lds_base_uniform), "v"(lane_bytes), "n"(OFF)
+               : "m0", "s98", "s99", "scc");
+}
+
 // slots 2.. of an encoding register file: sin (half 0) / cos (half 1) of 2^f * coordinate, f = 0 .. NF-1, by the
 // double-angle recurrence of trig.h from one fp64 sincos per coordinate
 template <int NF>

@@ -75,7 +75,11 @@ struct NetX6 {
                                              float& sigma, float (&rgb)[3], float (&insv)[16 * T]) {
     float pe[32], qe[16];
     point_encodings(f, mc, h, pe, qe);
-    x6_network<T, false>(c, cst, pe, qe, h, f.sigma_only != 0, nullptr, sigma, rgb, insv);
+    if (x6_network<T, false>(c, cst, pe, qe, h, f.sigma_only != 0, nullptr, sigma, rgb, insv)) {
+      rgb[0] = 0.f; rgb[1] = 0.f; rgb[2] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16 * T; ++i) insv[i] = 0.f;
+    }
   }
 };
 

@@ -42,11 +42,24 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(const FieldArgs a)
   }
 
   float sigma, rgb[3], insv[16 * T];
-  x6_network<T, SAVE>(c, cst, pe, qe, h, a.sigma_only != 0, rec, sigma, rgb, insv);
-
-  // ---- raw = cat([rgb, density, ins]) (dm_nerf.py:105); density only: [0, 0, 0, sigma, 0 ...]
-  if (valid) {
-    float* const row = a.raw + m * (4 + a.ins_ch);
+  float* const row = valid ? a.raw + m * (4 + a.ins_ch) : nullptr;
+  if (x6_network<T, SAVE>(c, cst, pe, qe, h, a.sigma_only != 0, rec, sigma, rgb, insv)) {
+    // density only: raw = [0, 0, 0, sigma, 0 ...]
+    if (row != nullptr) {
+      if (h == 0) {
+        row[0] = 0.f; row[1] = 0.f; row[2] = 0.f;
+        row[3] = sigma;
+      }
+#pragma unroll
+      for (int i = 0; i < 16 * T; ++i) {
+        const int ch = feat_of(i, 0) + 4 * h;
+        if (ch < a.ins_ch) row[4 + ch] = 0.f;
+      }
+    }
+    return;
+  }
+  // ---- raw = cat([rgb, density, ins]) (dm_nerf.py:105)
+  if (row != nullptr) {
     if (h == 0) {
       row[0] = rgb[0]; row[1] = rgb[1]; row[2] = rgb[2];
       row[3] = sigma;
@@ -57,9 +70,8 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(const FieldArgs a)
       if (ch < a.ins_ch) row[4 + ch] = insv[i];
     }
   }
-  // LDS-DMA still in flight (the density-only exit; the clamped tail copies of the three-slot ring) must land before
-  // the LDS is released
-  if (a.sigma_only || kX6Slots == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // the clamped tail copies of the three-slot ring must land before the LDS is released
+  if (kX6Slots == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 template <bool SAVE>

@@ -79,15 +79,36 @@ __device__ __forceinline__ void x6_stage_begin(Ctx6& c) {
   ++c.g;
 }
 
-// piece q (0..11) of this wave's share of the stage kX6Slots - 1 ahead of the running one (the running stage is c.g - 1
+// piece Q (0..11) of this wave's share of the stage kX6Slots - 1 ahead of the running one (the running stage is c.g - 1
 // after x6_stage_begin); past the end of the stream the source clamps to the last stage (the copy lands in a slot nobody
-// reads any more)
-__device__ __forceinline__ void x6_load_piece(const Ctx6& c, int q) {
+// reads any more).  The two bases are per-stage values (one scalar expression each per stage, common to its 12 pieces);
+// the piece's own offset is added inside the asm statement (glds16_at).
+template <int Q>
+__device__ __forceinline__ void x6_load_piece(const Ctx6& c) {
   const int gt = c.g + kX6Slots - 2;
   const int g = gt < c.G ? gt : c.G - 1;
-  const char* src = c.stream + (long)g * kX6StageBytes + (c.wave_s * kX6PiecesPerWave + q) * 1024;
-  char* dst = c.lds + x6_slot(gt) * kX6StageBytes + (c.wave_s * kX6PiecesPerWave + q) * 1024;
-  glds16_u(src, (unsigned)c.lane * 16u, dst);
+  const char* src = c.stream + ((unsigned)g * (unsigned)kX6StageBytes + (unsigned)(c.wave_s * kX6PiecesPerWave * 1024));
+  const unsigned dst = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)c.lds +
+                       (unsigned)(x6_slot(gt) * kX6StageBytes + c.wave_s * kX6PiecesPerWave * 1024);
+  glds16_at<Q * 1024>(src, (unsigned)c.lane * 16u, dst);
+}
+
+// the same with the piece number as a (constant-folded) value
+__device__ __forceinline__ void x6_piece(const Ctx6& c, int q) {
+  switch (q) {
+    case 0: x6_load_piece<0>(c); break;
+    case 1: x6_load_piece<1>(c); break;
+    case 2: x6_load_piece<2>(c); break;
+    case 3: x6_load_piece<3>(c); break;
+    case 4: x6_load_piece<4>(c); break;
+    case 5: x6_load_piece<5>(c); break;
+    case 6: x6_load_piece<6>(c); break;
+    case 7: x6_load_piece<7>(c); break;
+    case 8: x6_load_piece<8>(c); break;
+    case 9: x6_load_piece<9>(c); break;
+    case 10: x6_load_piece<10>(c); break;
+    default: x6_load_piece<11>(c); break;
+  }
 }
 
 // Exact three-way split of a value pair into elements j, j+1 of the hi / mid / lo fragments: one packed conversion per
@@ -246,10 +267,10 @@ __device__ __forceinline__ void layer_x6(Ctx6& c, f32x16* out, const float* bias
       out[t] = P6::mfma(ah[ar], bm, out[t]);
       out[t] = P6::mfma(ah[ar], bh, out[t]);
       if (dma) {
-        if (gi < kX6PiecesPerWave) x6_load_piece(c, gi);
+        if (gi < kX6PiecesPerWave) x6_piece(c, gi);
         if (gi + 1 == groups) {                 // a short stage still owes the rest of its pieces
 #pragma unroll
-          for (int q = gi + 1; q < kX6PiecesPerWave; ++q) x6_load_piece(c, q);
+          for (int q = gi + 1; q < kX6PiecesPerWave; ++q) x6_piece(c, q);
         }
       }
       if (ks + 1 < NK) {                        // the next k-step's operand fragments, a pair (or more) per tile
@@ -269,10 +290,10 @@ __device__ __forceinline__ void layer_x6(Ctx6& c, f32x16* out, const float* bias
 //   cst    constant section in LDS;  pe / qe: the encoding registers of point_encodings()
 //   rec    SAVE (training): this wave's save record, lane offset included (field_layout.h "Training")
 // Outputs (valid in both lane halves): sigma, rgb[3], and insv[i] = instance logit of channel feat_of(i, 0) + 4 h
-// (i < 16 T).  With sigma_only the colour and instance branches (29 % of the network) are skipped and rgb / insv come
-// back as zeros.
+// (i < 16 T).  With sigma_only the network stops behind its density head (the colour and instance branches are 29 % of
+// it) and returns true: sigma is valid, rgb / insv are not written.
 template <int T, bool SAVE>
-__device__ __forceinline__ void x6_network(Ctx6& c, const float* cst, const float* pe, const float* qe, int h,
+__device__ __forceinline__ bool x6_network(Ctx6& c, const float* cst, const float* pe, const float* qe, int h,
                                            bool sigma_only, float* rec, float& sigma, float (&rgb)[3],
                                            float (&insv)[16 * T]) {
   unsigned msk[4] = {0u, 0u, 0u, 0u};
@@ -302,19 +323,27 @@ __device__ __forceinline__ void x6_network(Ctx6& c, const float* cst, const floa
     }
   }
   // ---- mlps.5 on cat([h, input_pts]) (skip connection, dm_nerf.py:86-87), mlps.6, mlps.7: A -> B -> A -> B
+  // (c.g = ...: the stage number as a constant again behind the rolled loop -- the running counter is the same number,
+  // but as a loop-carried value it makes every later LDS-DMA address a scalar expression of it, which the compiler
+  // precomputes behind the loop, 324 of them, and parks in vector-register lanes: 580 v_writelane / v_readlane per pass)
+  c.g = kX6StageL5;
   if constexpr (SAVE) {
     layer_x6<8, 16, 4, K8, true, false, false>(c, accB, cst + kConstBias8 + 5 * 256 + h * 128, s_a, s_pe, nullptr,
                                                SaveRows<true>{rec + save_h(5) * 64, msk});
     x6_flush_mask<4>(rec + save_mask(5) * 64, msk);
+    c.g = kX6StageL6;
     layer_x6<8, 16, 0, K8, true, false, false>(c, accA, cst + kConstBias8 + 6 * 256 + h * 128, s_b, s_pe, nullptr,
                                                SaveRows<true>{rec + save_h(6) * 64, msk});
     x6_flush_mask<4>(rec + save_mask(6) * 64, msk);
+    c.g = kX6StageL6 + 8;
     layer_x6<8, 16, 0, K8, true, false, false>(c, accB, cst + kConstBias8 + 7 * 256 + h * 128, s_a, s_pe, nullptr,
                                                SaveRows<true>{rec + save_h(7) * 64, msk});
     x6_flush_mask<4>(rec + save_mask(7) * 64, msk);
   } else {
     layer_x6<8, 16, 4, K8, true, false, false>(c, accB, cst + kConstBias8 + 5 * 256 + h * 128, s_a, s_pe);
+    c.g = kX6StageL6;
     layer_x6<8, 16, 0, K8, true, false, false>(c, accA, cst + kConstBias8 + 6 * 256 + h * 128, s_b, s_pe);
+    c.g = kX6StageL6 + 8;
     layer_x6<8, 16, 0, K8, true, false, false>(c, accB, cst + kConstBias8 + 7 * 256 + h * 128, s_a, s_pe);
   }
 
@@ -324,11 +353,15 @@ __device__ __forceinline__ void x6_network(Ctx6& c, const float* cst, const floa
   for (int i = 0; i < 128; ++i) sigma = fmaf(relu_bits(accB[i >> 4][i & 15]), dw[i], sigma);
   sigma += __shfl_xor(sigma, 32);
   sigma += cst[kConstDensB];
+  // density is all the caller wants (the coarse pass of an image loop feeds the resampler): out, with rgb / insv
+  // untouched.  A run-time branch that LEAVES (the stand-alone kernel stores its row and ends there): as a compile-time
+  // variant, or with the two paths joining again behind the network, the compiler treats the 6,600 MFMAs as one
+  // region, stretches live ranges across it and spills 100+ vector registers.
+  if (sigma_only) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next stage's LDS-DMA must land before the LDS is let go of
+    return true;
+  }
   rgb[0] = 0.f; rgb[1] = 0.f; rgb[2] = 0.f;
-#pragma unroll
-  for (int i = 0; i < 16 * T; ++i) insv[i] = 0.f;
-  if (sigma_only) return;      // density is all the caller wants (the coarse pass of an image loop feeds the resampler);
-                               // the next stage's LDS-DMA is still in flight: the caller waits (vmcnt(0)) before it lets go of the LDS
 
   // ---- rgb_feature_linear on h8 (no activation behind it, dm_nerf.py:89) -> A.  The upper half of h8 (tiles 4..7 of
   //      B) stays behind in vector registers (the position encoding's are free by now): its four tiles take the output
@@ -340,15 +373,18 @@ __device__ __forceinline__ void x6_network(Ctx6& c, const float* cst, const floa
   const SrcH8 s_h8{accB, h8};
   const SrcTiles s_2{acc2};
   f32x16 acc3[T];
+  c.g = kX6StageRgbF;
   if constexpr (SAVE) {
     layer_x6<8, 16, 0, K8, true, true, false>(c, accA, cst + kConstBias8 + 8 * 256 + h * 128, s_b, s_pe, h8,
                                               SaveRows<true>{rec + save_h(8) * 64, msk});
     x6_flush_mask<4>(rec + save_mask(8) * 64, msk);
     // ---- rgb_feature_linears.0 on cat([feature, dirs]) -> 128, ReLU (dm_nerf.py:90-93); rgb_linear on the VALU (:102)
+    c.g = kX6StageRgbH;
     layer_x6<4, 16, 2, K4, false, false, false>(c, acc2, cst + kConstBias4 + h * 64, s_a, s_qe, nullptr,
                                                 SaveRows<false>{rec + kSaveFeat * 64, msk});
   } else {
     layer_x6<8, 16, 0, K8, true, true, false>(c, accA, cst + kConstBias8 + 8 * 256 + h * 128, s_b, s_pe, h8);
+    c.g = kX6StageRgbH;
     layer_x6<4, 16, 2, K4, false, false, false>(c, acc2, cst + kConstBias4 + h * 64, s_a, s_qe);
   }
 #pragma unroll
@@ -370,20 +406,25 @@ __device__ __forceinline__ void x6_network(Ctx6& c, const float* cst, const floa
   }
   // ---- ins_feature_linear on the same trunk output (h.detach(), dm_nerf.py:95-96), no activation -> A;
   //      ins_feature_linears.0 -> 128, ReLU (:97-99); ins_linear -> ins_num + 1 (:103)
+  c.g = kX6StageInsF;
   layer_x6<8, 16, 0, K8, false, false, false>(c, accA, cst + kConstBias8 + 9 * 256 + h * 128, s_h8, s_pe);
+  c.g = kX6StageInsH;
   if constexpr (SAVE) {
     layer_x6<4, 16, 0, K4, false, false, false>(c, acc2, cst + kConstBias4 + 128 + h * 64, s_a, s_pe, nullptr,
                                                 SaveRows<false>{rec + kSaveInsF * 64, msk});
+    c.g = kX6StageInsO;
     layer_x6<T, 8, 0, x6_inso_ksteps_per_stage(T), true, false, true>(c, acc3, cst + kConstBiasO + h * 64, s_2, s_pe, nullptr,
                                                                      SaveRows<true>{rec + kSaveI1 * 64, msk});
     x6_flush_mask<2>(rec + kSaveMaskI1 * 64, msk);
   } else {
     layer_x6<4, 16, 0, K4, false, false, false>(c, acc2, cst + kConstBias4 + 128 + h * 64, s_a, s_pe);
+    c.g = kX6StageInsO;
     layer_x6<T, 8, 0, x6_inso_ksteps_per_stage(T), true, false, true>(c, acc3, cst + kConstBiasO + h * 64, s_2, s_pe);
   }
 
 #pragma unroll
   for (int i = 0; i < 16 * T; ++i) insv[i] = acc3[i >> 4][i & 15];
+  return false;
 }
 
 }  // namespace dmn

@@ -436,6 +436,18 @@ def main():
         out["headline_over_exact_fp32_mode"] = value / out["exact_fp32_mode"]["value"]
     if exact_rgb is not None and ns.precision != "fp32":
         out["whole_image_vs_fp32_mode"] = deviation_stats(rgb.reshape(-1, 3), exact_rgb.reshape(-1, 3))
+    if world == 1 and not ns.no_split and ns.precision != "fp32":
+        # the headline arithmetic with the coarse pass reduced to density (render_image(image_only=True)): bit-identical
+        # images, the coarse network's colour / instance heads are not evaluated.  Reported beside, never as `value`.
+        only = make_step(ns.precision, image_only=True)
+        rgb_only, _ = only()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        only()
+        torch.cuda.synchronize()
+        dt_only = time.perf_counter() - t1
+        out["image_only_coarse_pass"] = {"value": H * W / dt_only, "unit": "rays/s", "ms_per_step": dt_only * 1e3,
+                                         "identical_image": bool(torch.equal(rgb_only, rgb))}
     modes = [m for m in modes if m != "fp32"]
     if modes:
         out["split_precision_modes"] = {}

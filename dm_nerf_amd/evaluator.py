@@ -113,7 +113,8 @@ class _InsCriterionFn(torch.autograd.Function):
             v = int(host[0, 0])
             if reduce is not None and host[0, 1] != 0.0:
                 # the flag was summed with the histogram: every rank is here, none re-enters the collectives
-                raise ValueError("sharded ins_criterion needs labels in [0, ins_num] on every shard")
+                raise ValueError("sharded ins_criterion needs labels in [0, ins_num] on every shard (and no more distinct "
+                                 "labels than instance columns)")
             if host[0, 1] != 0.0 or v == 0:
                 return (None,) * (4 * m)
             match = np.full((m, ins_num + k), -1, dtype=np.int32)
@@ -207,10 +208,15 @@ def ins_criterion(pred_ins: torch.Tensor, gt_labels: torch.Tensor, ins_num: int,
         v = int(valid.numel())                                                        # :24
         count = torch.bincount(classes, minlength=v).to(torch.float32)[:, None]
     else:
-        # labels present in ANY shard, in sorted order (torch.unique over the whole batch)
-        if n and (int(labels.min()) < 0 or int(labels.max()) > ins_num):
-            raise ValueError("sharded ins_criterion needs labels in [0, ins_num]")
-        per_label = reduce("ins_label_count", torch.bincount(labels, minlength=ins_num + 1).to(torch.float32))
+        # labels present in ANY shard, in sorted order (torch.unique over the whole batch).  A label outside [0, ins_num]
+        # on one shard must stop EVERY rank before the next collective: the flag rides behind the histogram (as in the
+        # kernels' form, dmn_ins_label_hist), so the summed flag is the same everywhere
+        ok = (labels >= 0) & (labels <= ins_num)
+        hist = torch.bincount(labels[ok], minlength=ins_num + 1).to(torch.float32)
+        hist = reduce("ins_label_count", torch.cat([hist, (~ok).any().to(torch.float32).reshape(1)]))
+        if float(hist[-1]) != 0.0:
+            raise ValueError("sharded ins_criterion needs labels in [0, ins_num] on every shard")
+        per_label = hist[:-1]
         present = per_label > 0
         v = int(present.sum())
         slot = torch.cumsum(present.long(), 0) - 1                                    # label -> row of the class axis

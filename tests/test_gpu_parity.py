@@ -1172,6 +1172,29 @@ def test_sharded_loss_heads_reproduce_the_unsharded_loss_and_gradient(fused):
     assert abs(alone[0] - whole[0]) > 1e-3 * abs(whole[0])
 
 
+@pytest.mark.parametrize("fused", [True, False])
+def test_sharded_instance_loss_stops_every_shard_on_a_label_out_of_range(fused):
+    """A label outside [0, ins_num] on ONE shard: the flag travels with the label histogram through the reduction, so the
+    clean shard raises too (on a real process group every rank leaves before the next collective; a rank-local check
+    would leave the others waiting in it)."""
+    n, ins_num = 64, 13
+    pred, labels = cases.criterion_case(n, ins_num, (0, 2, 3, 7, 12), 317)
+    bad = labels.copy()
+    bad[5] = ins_num + 4
+    lab_bad, lab_ok = torch.from_numpy(bad[:32]).to(DEV), torch.from_numpy(labels[32:]).to(DEV)
+    rec = _TwoShardReducer()                                                 # recording pass: the shard's own contribution
+    with pytest.raises(ValueError):                                          # the shard that holds the label
+        dm.ins_criterion(G(pred[:32]), lab_bad, ins_num, reduce=rec, fused=fused)
+    assert rec.own[0][0] == "ins_label_count" and float(rec.own[0][1][-1]) == 1.0
+    clean = _TwoShardReducer()
+    clean.other = rec.own                                                    # the clean shard sees the summed flag
+    with pytest.raises(ValueError):
+        dm.ins_criterion(G(pred[32:]), lab_ok, ins_num, reduce=clean, fused=fused)
+    # and both shards issued the same reductions before they stopped (the tensor-operation form reads the flag right
+    # behind the first one, the kernels' form with its one read-back behind the third)
+    assert clean.calls == len(rec.own) == (3 if fused else 1)
+
+
 def test_grad_bucket_receives_the_weight_gradients_in_place():
     """parallel.GradBucket: the weight-gradient kernel of both networks writes straight into the persistent flat
     buffer, p.grad are views of it after backward (nothing to concatenate or copy back), and the values equal a

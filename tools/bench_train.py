@@ -2,7 +2,7 @@
 """Training-step timing (BASELINE config 4): N_rand rays per step, stochastic path, Adam.  Prints one JSON line.
 Not the headline bench (bench.py is).
 
-    python tools/bench_train.py [--rays 4096 --steps 5 --precision fp32|bf16x3 --instance --penalize]
+    python tools/bench_train.py [--rays 4096 --steps 5 --precision bf16x6|fp32|bf16x3 --instance --penalize]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/bench_train.py --gpus N
 
 With N ranks the rays of a step are sharded (strong scaling: --rays is the global batch), every rank runs forward and
@@ -27,7 +27,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--gpus", type=int, default=1)
 ap.add_argument("--rays", type=int, default=4096, help="rays per optimisation step over all ranks (N_rand)")
 ap.add_argument("--steps", type=int, default=5)
-ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x6", "bf16x3", "fp16x3"])
+ap.add_argument("--precision", default="bf16x6", choices=["fp32", "bf16x6", "bf16x3", "fp16x3"])
 ap.add_argument("--instance", action="store_true", help="add the instance-matching loss on random labels")
 ap.add_argument("--assign", default="device", choices=["host", "device"],
                 help="Hungarian step of the instance loss: scipy on the host (one wait for the device per step) or the kernel")

@@ -157,7 +157,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void composite_kernel(Composit
     const int cnt = min(64, S - s0);
     const int nfl = cnt * C;
     const float* src = rawr + (long)s0 * C;
-    __syncthreads();   // previous slab fully consumed (uniform trip count across the block)
+    // The slab is this wave's own: a wave's LDS operations execute in order, so what the copy below and the reads of
+    // composite_slab() need is that the compiler keeps them in program order (wave-scope fence) -- not a workgroup
+    // barrier, which would tie the four rays of a block to the slowest of them twice per slab.
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
       const int nv = nfl >> 2;
       for (int i = lane; i < nv; i += 64)
@@ -166,7 +170,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void composite_kernel(Composit
     } else {
       for (int i = lane; i < nfl; i += 64) slab[i] = src[i];
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     const float w = composite_slab<false>(st, slab, zr, s0, cnt, S, C, norm, lane);
     if (lane < cnt && ray_ok && a.weights) a.weights[n * S + s0 + lane] = w;
   }

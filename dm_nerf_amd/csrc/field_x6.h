@@ -44,6 +44,9 @@ typedef P6::frag frag;
 #ifndef DMN_X6_ORDER
 #define DMN_X6_ORDER 0
 #endif
+#ifndef DMN_X6_NINE
+#define DMN_X6_NINE 0
+#endif
 constexpr int kX6Slots = DMN_X6_SLOTS;
 static_assert(kX6Slots == 2 || kX6Slots == 3, "two or three stage slots");
 constexpr bool kX6CrossBarrier = kX6Slots == 3 && DMN_X6_XBAR;
@@ -263,6 +266,11 @@ __device__ __forceinline__ void layer_x6(Ctx6& c, f32x16* out, const float* bias
         al[ar ^ 1] = *reinterpret_cast<const frag*>(nb + 2048);
       }
       __builtin_amdgcn_sched_barrier(0);        // keep the prefetch above this group's MFMAs
+#if DMN_X6_NINE                                 // experiment: all nine products (the three dropped ones first)
+      out[t] = P6::mfma(al[ar], bl, out[t]);
+      out[t] = P6::mfma(al[ar], bm, out[t]);
+      out[t] = P6::mfma(am[ar], bl, out[t]);
+#endif
 #if DMN_X6_ORDER == 0
       out[t] = P6::mfma(al[ar], bh, out[t]);    // small terms first
       out[t] = P6::mfma(ah[ar], bl, out[t]);

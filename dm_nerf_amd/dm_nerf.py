@@ -130,6 +130,7 @@ class DM_NeRF(nn.Module):
         if flat.dtype != torch.float32 or flat.numel() != n or not flat.is_contiguous():
             raise ValueError(f"gradient buffer must be {n} contiguous float32")
         self._grad_flat = flat
+        self._grad_lent = False
 
     def grad_buffer(self):
         """The adopted flat gradient buffer if the kernel may write it now, else None: no parameter holds a gradient

@@ -55,7 +55,8 @@ class GradBucket:
     type, a second backward into existing grads) are copied in once and re-pointed."""
 
     def __init__(self, models):
-        self.params = [p for m in models for p in m.parameters()]
+        self.models = list(models)
+        self.params = [p for m in self.models for p in m.parameters()]
         if not self.params:
             raise ValueError("no parameters")
         dev = self.params[0].device
@@ -65,7 +66,7 @@ class GradBucket:
             self.views.append(self.flat[offset:offset + p.numel()].view_as(p))
             offset += p.numel()
         offset = 0
-        for m in models:
+        for m in self.models:
             n = sum(p.numel() for p in m.parameters())
             if hasattr(m, "adopt_grad_buffer"):
                 m.adopt_grad_buffer(self.flat[offset:offset + n])
@@ -78,6 +79,9 @@ class GradBucket:
             elif p.grad.data_ptr() != v.data_ptr():
                 v.copy_(p.grad)
             p.grad = v
+        for m in self.models:       # whatever was lent to a backward node has been consumed by now (a backward pass that
+            if hasattr(m, "_grad_lent"):      # raised half way never ran the engine callback that returns the buffer)
+                m._grad_lent = False
 
     def allreduce(self, group=None, scale: float = 1.0) -> int:
         """SUM over ranks, then ``* scale`` (1/world for replicated-mean losses; 1.0 when every rank's loss terms are

@@ -14,6 +14,7 @@ from .dm_nerf import DM_NeRF, Embedder, get_embedder
 from .evaluator import img2mse, ins_criterion, ins_criterion_many, mse2psnr
 from .helpers import get_rays_k, get_select_crop, get_select_full, sample_pdf, z_val_sample
 from .manipulator import exchanger, manipulator, manipulator_nerf, manipulator_render
+from .ops import DEFAULT_PRECISION, PRECISIONS
 from .penalizer import emptiness_penalizer, ins_penalizer
 from .render import dm_nerf, render_train
 from .tester import render_image, render_test
@@ -28,5 +29,5 @@ __all__ = [
     "HipLibraryError", "LIB_PATH", "load_library", "create_nerf", "default_args", "DM_NeRF", "Embedder",
     "get_embedder", "emptiness_penalizer", "ins_penalizer", "ins_criterion", "ins_criterion_many", "img2mse", "mse2psnr", "get_rays_k", "get_select_full", "get_select_crop", "sample_pdf", "z_val_sample", "manipulator_nerf", "manipulator_render", "exchanger", "manipulator",
     "dm_nerf", "render_train", "render_image", "render_test", "render", "raw2outputs", "render_path", "parallel",
-    "trainer",
+    "trainer", "DEFAULT_PRECISION", "PRECISIONS",
 ]

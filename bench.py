@@ -212,7 +212,7 @@ def field_roofline(profile, precision: str, elapsed: float):
 
 
 def arithmetic_check(nerf, params, device, n_points: int = 4096):
-    """How far each arithmetic is from the exact result: the fine network on `n_points` encoded sample points of the
+    """(CPU-baseline leg.)  How far each arithmetic is from the exact result: the fine network on `n_points` encoded sample points of the
     benchmark scene, every kernel mode and the CPU oracle's fp32 evaluation (the reference's op sequence) against the
     CPU oracle run in fp64 on the same fp32 parameters.  max |raw - raw64| / max |raw64|."""
     from oracle import dmnerf_cpu as oracle
@@ -470,9 +470,6 @@ def main():
         entry["image_only_coarse_pass"] = {"value": H * W / dt_only, "unit": "rays/s", "ms_per_step": dt_only * 1e3,
                                            "identical_image": bool(torch.equal(rgb_only, rgb_m))}
         out["split_precision_modes"][mode] = entry
-    if world == 1 and not ns.no_split:
-        out["arithmetic_check"] = arithmetic_check(nerf, params, device)
-
     if world == 1 and not ns.no_train_leg:
         out["training_step"] = training_leg(nerf, K, poses[0], device)
 
@@ -488,6 +485,8 @@ def main():
                       f"({ns.cpu_rays // CPU_CHUNK} chunks) through oracle/dmnerf_cpu.py (PyTorch CPU fp32, same op "
                       "sequence as the reference), after a 256-ray warm-up"}
         out["gpu_over_cpu"] = value / cpu_rps
+        # part of the CPU leg: the oracle in fp64 as the checker of every arithmetic (and of its own fp32 evaluation)
+        out["arithmetic_check"] = arithmetic_check(nerf, params, device)
         # deviation of every mode from the CPU oracle on the sample rays, the same chunking on both sides
         # (relative = per-ray worst element over max|oracle|; the oracle itself moves by 2e-4 against an fp64 run of the
         # reference behind the sampler)

@@ -409,6 +409,27 @@ def test_image_loop_with_ragged_tail_matches_reference_golden(golden, precision)
 
 
 # ---- BASELINE sizes: size-independent properties ------------------------------------------------
+def test_full_size_launch_of_the_default_arithmetic_agrees_with_the_exact_kernel():
+    """One launch of the bench's size (65536 rays x 192 samples = 12.6 M points through the fine network): the bf16x6
+    kernel against the exact-fp32 MFMA kernel on every raw value -- both are fp32-grade, so they differ by accumulation
+    rounding only --, deterministic run to run, and the density-only mode returns the same densities."""
+    n, s = 65536, 192
+    _, _, _, fine, _ = nets(13, 0, 1)
+    rng = np.random.default_rng(123)
+    o = G(rng.uniform(-1, 1, size=(n, 3)).astype(np.float32))
+    d = G(rng.standard_normal((n, 3)).astype(np.float32))
+    z = torch.sort(torch.rand(n, s, device=DEV) * (cases.FAR - cases.NEAR) + cases.NEAR, -1)[0]
+    exact = ops.field_rays(o, d, z, fine.blob("fp32"), 13, "fp32")
+    x6 = ops.field_rays(o, d, z, fine.blob("bf16x6"), 13, "bf16x6")
+    scale = float(exact.abs().max())
+    assert torch.isfinite(x6).all()
+    worst = float((x6 - exact).abs().max()) / scale
+    assert worst < 3e-6, worst                                   # observed ~1e-6 (fp32 accumulation order)
+    assert torch.equal(x6, ops.field_rays(o, d, z, fine.blob("bf16x6"), 13, "bf16x6"))
+    dens = ops.field_rays(o, d, z, fine.blob("bf16x6"), 13, "bf16x6", sigma_only=True)
+    assert torch.equal(dens[..., 3], x6[..., 3])
+
+
 def test_full_size_chunk_properties():
     Hh = W = 800
     pos, view, coarse, fine, args = nets(13, 0, 1)

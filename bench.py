@@ -14,8 +14,11 @@ against an fp64 evaluation).  The exact-fp32 MFMA mode (``exact_fp32_mode``) and
 MFMAs per product, ``split_precision_modes``) are timed over the same --steps right after it and reported beside it,
 all with their deviation statistics against the CPU oracle.
 Inputs are synthetic (no dataset / checkpoint exists offline): DM-SR style intrinsics, orbit
-poses, PCG64-seeded weights.  With N > 1 (launched by torch.distributed.run,
-one process per GPU) every rank renders its own pose: no data-path collective, weak scaling.
+poses, PCG64-seeded weights.  With N > 1 -- one process per GPU, started by
+torch.distributed.run or, when no launcher set WORLD_SIZE, by this script itself as a child process -- every rank
+renders its own pose (``--scaling weak``, the default: no data-path collective) or a contiguous ray range of ONE image
+(``--scaling strong``: ray-sharded, the finished maps all-gathered inside the timed region and checked bit for bit
+against the one-rank image; networks/tester.py:54-85 is the loop that is cut).
 
 Prints ONE JSON line on rank 0."""
 from __future__ import annotations
@@ -26,11 +29,27 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def _self_launch_if_needed():
+    """`python bench.py --gpus N` without a launcher: start N ranks under torch.distributed.run as a child process and
+    exit with its status.  Runs before torch is imported -- the parent never touches the GPU (dm_nerf_amd/launch.py is
+    loaded by path: importing the package would import torch)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_dmn_launch", os.path.join(ROOT, "dm_nerf_amd", "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if mod.needs_self_launch(sys.argv[1:]):
+        sys.exit(mod.self_launch(os.path.abspath(__file__), sys.argv[1:]))
+
+
+if __name__ == "__main__":
+    _self_launch_if_needed()
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 import dm_nerf_amd as dm  # noqa: E402
 from dm_nerf_amd import ops  # noqa: E402
@@ -286,6 +305,49 @@ def cpu_baseline(K, pose, params, sample_rays: int, chunk: int, near: float = 4.
     return sample_rays / dt, {k: torch.cat(v, 0) for k, v in outs.items()}
 
 
+def replica_leg(device, precision: str, chunk: int, steps: int = 3):
+    """BASELINE config 3's shape beside the headline (outside its timed region): Replica room_0 geometry -- 640x480,
+    ins_num 93 (98-channel raw rows), near 0 / far 6.5 (configs/train/replica/room_0.txt:13-14, loader_replica.py) --
+    `steps` images through the chained kernels and through the fused field + compositing kernels, with the roofline of
+    composite_wide_kernel (rows wider than 32 channels) from the chained run's HIP events."""
+    from types import SimpleNamespace
+    from dm_nerf_amd import synthetic
+    h, w, ins_num, near, far = 480, 640, 93, 0.0, 6.5
+    args = dm.default_args(ins_num=ins_num, N_samples=N_SAMPLES, N_importance=N_IMPORTANCE, N_test=4096, near=near, far=far,
+                           device=device)
+    pos, view, coarse, fine, args = dm.create_nerf(args)
+    coarse.load_state_dict(synthetic.make_params(ins_num, 0))
+    fine.load_state_dict(synthetic.make_params(ins_num, 1))
+    coarse.eval(); fine.eval()
+    hwk, pose = [h, w, synthetic.dmsr_intrinsics(h, w)], synthetic.study_pose(0)
+    c_ch = 5 + ins_num
+    out = {"workload": f"Replica room_0 shape {w}x{h}, 64+128, ins_num={ins_num} ({c_ch}-channel rows), near {near} / far {far}",
+           "precision": precision, "steps": steps, "chunk_rays": chunk}
+    images = {}
+    for name, fused in (("chained", False), ("fused", True)):
+        a = SimpleNamespace(**{**vars(args), "precision": precision, "fused": fused})
+        step = lambda: dm.render_image(pos, view, coarse, fine, pose, hwk, a, chunk=chunk)
+        elapsed, profile, (rgb, ins) = timed_images(step, steps, 1, torch.cuda.synchronize)
+        images[name] = (rgb, ins)
+        entry = {"value": steps * h * w / elapsed, "unit": "rays/s", "ms_per_step": elapsed / steps * 1e3}
+        n_c, t_c, pts_c = kernel_stats(profile, "composite")
+        if n_c:
+            per_ray = composite_bytes(1, N_SAMPLES, c_ch) + composite_bytes(1, N_SAMPLES + N_IMPORTANCE, c_ch)
+            nbytes = (pts_c // (2 * N_SAMPLES + N_IMPORTANCE)) * per_ray
+            entry["roofline_composite"] = {
+                "kernel": "composite_wide_kernel (rows straight from global memory, lane per channel)", "bound": "hbm",
+                "achieved": nbytes / t_c / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": nbytes / t_c / 1e9 / PEAK_HBM_GBS,
+                "traffic": None, "launches": n_c, "avg_launch_ms": t_c / n_c * 1e3, "algorithmic_bytes_per_launch": nbytes / n_c}
+            meas = measured_traffic(f"replica_chunk{chunk}")
+            if meas is not None:
+                entry["roofline_composite"]["traffic"] = meas["hbm_bytes_per_launch"]
+                entry["roofline_composite"]["traffic_source"] = meas["source"]
+        out[name] = entry
+    out["fused_bit_identical_to_chained"] = bool(torch.equal(images["chained"][0], images["fused"][0])
+                                                 and torch.equal(images["chained"][1], images["fused"][1]))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -316,6 +378,12 @@ def main():
                     help="split-precision modes: field + compositing (+ resampling) fused in one kernel (`raw` never in "
                          "HBM; same bits) or the chained kernels; auto = render_image's rule (fused for rows wider than 32 "
                          "channels)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = one image per rank per step (image-sharded, no data-path collective); strong = ONE "
+                         "image per step, its flat ray range cut into N contiguous blocks (parallel.ray_shard), every rank "
+                         "renders its block and the finished maps are all-gathered (RCCL) inside the timed region")
+    ap.add_argument("--no-side-legs", action="store_true",
+                    help="skip the chunk-4096 and Replica-shape measurements after the timed region (N = 1 only)")
     ap.add_argument("--no-train-leg", action="store_true",
                     help="skip the extra training-step measurement after the timed region (N = 1 only)")
     ns = ap.parse_args()
@@ -354,10 +422,27 @@ def main():
     pose = poses[rank % len(poses)]
     hwk = [H, W, K]
 
-    def make_step(precision, **kw):
+    strong = ns.scaling == "strong" and world > 1
+    if strong:
+        pose = poses[0]                      # every rank works on the same image
+
+    def make_step(precision, chunk=None, **kw):
         from types import SimpleNamespace
         a = SimpleNamespace(**{**vars(args), "precision": precision, "fused": {"auto": None, "on": True, "off": False}[ns.fused]})
-        return lambda: dm.render_image(pos, view, coarse, fine, pose, hwk, a, chunk=ns.chunk, **kw)
+        return lambda: dm.render_image(pos, view, coarse, fine, pose, hwk, a, chunk=chunk or ns.chunk, **kw)
+
+    def make_strong_step(precision):
+        """One image, ray-sharded: this rank's contiguous block of the flat ray range, then the all-gather of the maps."""
+        from dm_nerf_amd.parallel import gather_rays, ray_shard
+        block = ray_shard(H * W, rank, world)
+        local = make_step(precision, ray_range=block)
+
+        def step():
+            rgb_l, ins_l = local()
+            rgb_g = gather_rays(rgb_l, H * W)
+            ins_g = gather_rays(ins_l, H * W)
+            return rgb_g.reshape(H, W, 3), ins_g.reshape(H, W, ins_g.shape[-1])
+        return step
 
     def barrier():
         if dist is not None:
@@ -365,10 +450,15 @@ def main():
         torch.cuda.synchronize()
 
     # ---- the timed region: --warmup untimed images, then exactly --steps images
-    elapsed, profile, (rgb, ins) = timed_images(make_step(ns.precision), ns.steps, ns.warmup, barrier)
+    headline_step = make_strong_step(ns.precision) if strong else make_step(ns.precision)
+    elapsed, profile, (rgb, ins) = timed_images(headline_step, ns.steps, ns.warmup, barrier)
     if dist is not None:
         from dm_nerf_amd.parallel import max_over_ranks
         elapsed = max_over_ranks(elapsed, device)
+    sharded_equal = None
+    if strong and rank == 0:                 # outside the timed region: the same image on one rank, bit for bit
+        rgb_1, ins_1 = make_step(ns.precision)()
+        sharded_equal = bool(torch.equal(rgb_1, rgb) and torch.equal(ins_1, ins))
 
     if rank != 0:
         if dist is not None:
@@ -376,7 +466,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    rays_total = world * ns.steps * H * W
+    rays_total = (1 if strong else world) * ns.steps * H * W
     value = rays_total / elapsed
     n_c, t_c, pts_c = kernel_stats(profile, "composite")
     c_ch = 5 + INS_NUM
@@ -393,11 +483,14 @@ def main():
         "metric": f"rays/sec, {'DM-SR study 800x800' if ns.workload == 'study' else scene}, 64+128 samples (PSNR vs "
                   "reference path in `psnr_vs_cpu_oracle_db`)",
         "value": value, "unit": "rays/s", "n_gpus": world, "steps": ns.steps, "warmup": ns.warmup,
-        "ms_per_step": elapsed / ns.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": elapsed / ns.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": dtype_names[ns.precision], "data": "synthetic",
         "config": {"workload": f"{scene}, 64+128 hierarchical, 8x256 field, RGB+sigma+instance head "
-                               f"(ins_num={INS_NUM}), 1 image per GPU per step", "chunk_rays": ns.chunk,
-                   "precision": ns.precision, "parallelism": f"ray/image-sharded x{world}, no collective"},
+                               f"(ins_num={INS_NUM}), " + ("1 image per step, ray-sharded over the GPUs" if strong
+                                                           else "1 image per GPU per step"), "chunk_rays": ns.chunk,
+                   "precision": ns.precision,
+                   "parallelism": (f"one image ray-sharded x{world} (contiguous blocks), maps all-gathered in the timed region"
+                                   if strong else f"ray/image-sharded x{world}, no collective")},
         "roofline": field_roofline(profile, ns.precision, elapsed),
         "roofline_composite": {"kernel": ("composite_wide_kernel (rows straight from global memory, lane per channel)"
                                           if c_ch > 32 else "composite_kernel (LDS-staged slabs + wave product scan)"),
@@ -406,6 +499,11 @@ def main():
                                "avg_launch_ms": t_c / max(n_c, 1) * 1e3, "time_share_of_step": t_c / elapsed,
                                "algorithmic_bytes_per_launch": comp_bytes / max(n_c, 1)},
     }
+
+    if strong:
+        out["sharded_image_bit_equal_to_one_rank_image"] = sharded_equal
+        if not sharded_equal:
+            raise SystemExit("strong scaling: the ray-sharded image differs from the one-rank image")
 
     traffic_file = os.path.join(ROOT, "profiles", "composite_traffic.json")
     if os.path.exists(traffic_file):        # HBM bytes per composite launch from rocprofv3 PMC passes (tools/pmc_composite.sh)
@@ -470,6 +568,16 @@ def main():
         entry["image_only_coarse_pass"] = {"value": H * W / dt_only, "unit": "rays/s", "ms_per_step": dt_only * 1e3,
                                            "identical_image": bool(torch.equal(rgb_only, rgb_m))}
         out["split_precision_modes"][mode] = entry
+    if world == 1 and not ns.no_side_legs and ns.workload == "study":
+        # the reference's own chunk size (N_test = 4096, configs/test/dmsr/study.txt:10; networks/tester.py:62) over the
+        # same image: 157 dm_nerf calls per image instead of 10
+        n4 = max(1, min(ns.steps, 5))
+        e4, prof4, (rgb4, _) = timed_images(make_step(ns.precision, chunk=CPU_CHUNK), n4, 1, barrier)
+        out["chunk_4096"] = {"value": n4 * H * W / e4, "unit": "rays/s", "steps": n4, "ms_per_step": e4 / n4 * 1e3,
+                             "chunk_rays": CPU_CHUNK, "ratio_to_headline": (n4 * H * W / e4) / value,
+                             "identical_image": bool(torch.equal(rgb4, rgb)),
+                             "field_kernel_avg_launch_ms": field_roofline(prof4, ns.precision, e4)["avg_launch_ms"]}
+        out["replica_shape"] = replica_leg(device, ns.precision, ns.chunk)
     if world == 1 and not ns.no_train_leg:
         out["training_step"] = training_leg(nerf, K, poses[0], device)
 

@@ -97,6 +97,7 @@ __global__ __launch_bounds__(256, 1) void field_bwd_data_x3_kernel(const BwdX3Ar
 
   frag act_h[16], act_l[16], nxt_h[16], nxt_l[16];
   unsigned msk[4];
+  const_section_ready();      // the first layer reads its initial accumulators before its first stage barrier
 
   // ---- instance branch: ins_linear^T -> mask of ins_feature_linears.0 -> its transpose
   msk[0] = __float_as_uint(srec[(kSaveMaskI1 + 0) * 64]);

@@ -47,6 +47,13 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
+// The constant section (biases, VALU head weights) is LDS-DMA'd by all four waves at kernel start; a wave's own vmcnt
+// covers only its own chunks, so before anybody READS the section every wave waits for its pieces and the workgroup
+// meets once.  (The stage barriers of the layer loops come after the first bias reads.)
+__device__ __forceinline__ void const_section_ready() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
 // The same with the global address as wave-uniform base (SGPR pair) + 32-bit lane offset (one VGPR, the same for every
 // piece): `global_load_lds_dwordx4 v_off, s[base:base+1]`.  The base advances by scalar adds; the C builtin always takes
 // the per-lane 64-bit address form (a v_lshl_add_u64 per piece).  Inline asm: the compiler does not count these loads
@@ -70,12 +77,18 @@ __device__ __forceinline__ void glds16_u(const char* base_uniform, unsigned lane
 // destination (LDS, wave-uniform) bases are given: the offset is added to both INSIDE the statement (scalar adds into a
 // fixed SGPR pair and M0), so that per piece the compiler sees no address arithmetic at all -- given one expression per
 // piece it computes hundreds of them at the top of a basic block and parks them in vector-register lanes.
-template <int OFF>
+// NT: the load carries the non-temporal cache policy (streamed lines are the L2's first candidates for replacement).
+template <int OFF, bool NT = false>
 __device__ __forceinline__ void glds16_at(const char* src_base_uniform, unsigned lane_bytes, unsigned lds_base_uniform) {
   const unsigned long long a = (unsigned long long)src_base_uniform;
-  asm volatile("s_add_i32 m0, %2, %4\n\ts_add_u32 s98, %0, %4\n\ts_addc_u32 s99, %1, 0\n\tglobal_load_lds_dwordx4 %3, s[98:99]"
-               : : "s"((unsigned)a), "s"((unsigned)(a >> 32)), "s"(lds_base_uniform), "v"(lane_bytes), "n"(OFF)
-               : "m0", "s98", "s99", "scc");
+  if (NT)
+    asm volatile("s_add_i32 m0, %2, %4\n\ts_add_u32 s98, %0, %4\n\ts_addc_u32 s99, %1, 0\n\tglobal_load_lds_dwordx4 %3, s[98:99] nt"
+                 : : "s"((unsigned)a), "s"((unsigned)(a >> 32)), "s"(lds_base_uniform), "v"(lane_bytes), "n"(OFF)
+                 : "m0", "s98", "s99", "scc");
+  else
+    asm volatile("s_add_i32 m0, %2, %4\n\ts_add_u32 s98, %0, %4\n\ts_addc_u32 s99, %1, 0\n\tglobal_load_lds_dwordx4 %3, s[98:99]"
+                 : : "s"((unsigned)a), "s"((unsigned)(a >> 32)), "s"(lds_base_uniform), "v"(lane_bytes), "n"(OFF)
+                 : "m0", "s98", "s99", "scc");
 }
 
 // slots 2.. of an encoding register file: sin (half 0) / cos (half 1) of 2^f * coordinate, f = 0 .. NF-1, by the

@@ -190,6 +190,7 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x3_kernel(const FieldArgs a)
   typedef EpiSplitSave<P, true> Relu;
   typedef EpiSplitSave<P, false> Lin;
 
+  const_section_ready();      // mlps.0 reads its bias before its first stage barrier
   // ---- mlps.0: position encoding (4 k-steps) -> act
   layer_x3<P, 8, 4, 0>(c, cst + kConstBias8 + h * 128, pe_h, pe_l, pe_h, pe_l,
                        Relu{act_h, act_l, &amax, &sigma, dw, false, rec + save_h(1) * 64, msk, recu + save_h(1) * 64, lb});

@@ -10,6 +10,19 @@ using namespace dmn;
 
 namespace {
 
+// The workgroup's 128 raw rows are one contiguous block of `raw` (128 x C floats): they are gathered in LDS -- in the stage
+// buffers, which nobody reads any more -- and leave as full 16-byte-per-lane non-temporal stores.  Written row by row
+// from the lanes that hold the values (dword stores with a 72-byte stride), non-temporal stores reach memory as partial
+// writes (WRITE_SIZE 3.8 GB for 0.59 GB of rows per 8.2 M-point launch), and plain ones allocate in the XCD's L2 beside
+// the weight stream, which then misses 2.3x as often (experiments/README.md, Round 4).
+__device__ __forceinline__ void store_rows_coalesced(const float* stage, float* dst, int n_floats, int tid) {
+  const int nvec = n_floats >> 2;
+  for (int i = tid; i < nvec; i += 256)
+    __builtin_nontemporal_store(reinterpret_cast<const f32x4*>(stage)[i], reinterpret_cast<f32x4*>(dst) + i);
+  const int rest = n_floats & 3;
+  if (tid < rest) __builtin_nontemporal_store(stage[4 * nvec + tid], dst + 4 * nvec + tid);
+}
+
 // SAVE: also write the save record the backward kernels read (training; field_layout.h "Training")
 template <int T, bool SAVE>
 __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(const FieldArgs a) {
@@ -28,8 +41,7 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(const FieldArgs a)
   if (kX6Slots == 3) x6_load_stage(c, 1);
 
   const long m = ((long)blockIdx.x * 4 + wave_s) * 32 + p;
-  const bool valid = m < a.M;
-  const long mc = valid ? m : a.M - 1;
+  const long mc = m < a.M ? m : a.M - 1;
   float pe[32], qe[16];
   point_encodings(a, mc, h, pe, qe);
   // training: this wave's save record, lane offset included
@@ -42,34 +54,41 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6_kernel(const FieldArgs a)
   }
 
   float sigma, rgb[3], insv[16 * T];
-  float* const row = valid ? a.raw + m * (4 + a.ins_ch) : nullptr;
+  const int C = 4 + a.ins_ch;
+  float* const stage = reinterpret_cast<float*>(lds);                 // the stage buffers, once the network is through
+  float* const row = stage + (wave_s * 32 + p) * C;
+  const long first = (long)blockIdx.x * 128;
+  const int n_out = (int)(a.M - first < 128 ? a.M - first : 128) * C;
   if (x6_network<T, SAVE>(c, cst, pe, qe, h, a.sigma_only != 0, rec, sigma, rgb, insv)) {
-    // density only: raw = [0, 0, 0, sigma, 0 ...]
-    if (row != nullptr) {
-      if (h == 0) {
-        row[0] = 0.f; row[1] = 0.f; row[2] = 0.f;
-        row[3] = sigma;
-      }
-#pragma unroll
-      for (int i = 0; i < 16 * T; ++i) {
-        const int ch = feat_of(i, 0) + 4 * h;
-        if (ch < a.ins_ch) row[4 + ch] = 0.f;
-      }
-    }
-    return;
-  }
-  // ---- raw = cat([rgb, density, ins]) (dm_nerf.py:105)
-  if (row != nullptr) {
+    // density only: raw = [0, 0, 0, sigma, 0 ...].  (A branch of its own that ends the kernel: see x6_network.  The
+    // network waited for this wave's LDS-DMA of the next stage before it returned; behind the barrier all of it landed.)
+    __syncthreads();
     if (h == 0) {
-      row[0] = rgb[0]; row[1] = rgb[1]; row[2] = rgb[2];
+      row[0] = 0.f; row[1] = 0.f; row[2] = 0.f;
       row[3] = sigma;
     }
 #pragma unroll
     for (int i = 0; i < 16 * T; ++i) {
       const int ch = feat_of(i, 0) + 4 * h;
-      if (ch < a.ins_ch) row[4 + ch] = insv[i];
+      if (ch < a.ins_ch) row[4 + ch] = 0.f;
     }
+    __syncthreads();
+    store_rows_coalesced(stage, a.raw + first * C, n_out, tid);
+    return;
   }
+  // ---- raw = cat([rgb, density, ins]) (dm_nerf.py:105)
+  __syncthreads();                                   // every wave is done with the last weight stage (no DMA in flight)
+  if (h == 0) {
+    row[0] = rgb[0]; row[1] = rgb[1]; row[2] = rgb[2];
+    row[3] = sigma;
+  }
+#pragma unroll
+  for (int i = 0; i < 16 * T; ++i) {
+    const int ch = feat_of(i, 0) + 4 * h;
+    if (ch < a.ins_ch) row[4 + ch] = insv[i];
+  }
+  __syncthreads();
+  store_rows_coalesced(stage, a.raw + first * C, n_out, tid);
   // the clamped tail copies of the three-slot ring must land before the LDS is released
   if (kX6Slots == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }

@@ -71,6 +71,7 @@ __device__ __forceinline__ void x3_network(Ctx& c, const float* cst, const typen
   typedef EpiSplit<P, true, true> ReluDens;
   typedef EpiSplit<P, false, false> Lin;
 
+  const_section_ready();      // mlps.0 reads its bias before its first stage barrier
   // ---- mlps.0: position encoding (4 k-steps) -> act
   layer_x3<P, 8, 4, 0>(c, cst + kConstBias8 + h * 128, pe_h, pe_l, pe_h, pe_l, Relu{act_h, act_l, &amax, &sigma, dw});
   // ---- mlps.1 .. mlps.5 in ping-pong pairs (rolled: a layer pair is ~3000 instructions); mlps.5 (skip connection)

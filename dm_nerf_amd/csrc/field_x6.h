@@ -47,6 +47,15 @@ typedef P6::frag frag;
 #ifndef DMN_X6_NINE
 #define DMN_X6_NINE 0
 #endif
+// Layers (bit = layer id below) whose LDS-DMA pieces are issued with the non-temporal cache policy: the three-plane
+// stream of a network (4.03 MiB) is a cyclic working set just larger than the XCD's 4 MiB L2, which under LRU misses on
+// EVERY line; marking a part of it for early replacement leaves a remainder that fits and stays (experiments/README.md,
+// Round 4).  Ids: 0 mlps.0, 1 mlps.1-4, 2 mlps.5, 3 mlps.6, 4 mlps.7, 5 rgb_feature_linear, 6 rgb_feature_linears.0,
+// 7 ins_feature_linear, 8 ins_feature_linears.0, 9 ins_linear.  (The pieces a layer issues belong to the stage AFTER
+// the running one, so the marked range is shifted by one stage against the layer: irrelevant for the purpose.)
+#ifndef DMN_X6_NTMASK
+#define DMN_X6_NTMASK 0x380
+#endif
 constexpr int kX6Slots = DMN_X6_SLOTS;
 static_assert(kX6Slots == 2 || kX6Slots == 3, "two or three stage slots");
 constexpr bool kX6CrossBarrier = kX6Slots == 3 && DMN_X6_XBAR;
@@ -89,31 +98,32 @@ __device__ __forceinline__ void x6_stage_begin(Ctx6& c) {
 // after x6_stage_begin); past the end of the stream the source clamps to the last stage (the copy lands in a slot nobody
 // reads any more).  The two bases are per-stage values (one scalar expression each per stage, common to its 12 pieces);
 // the piece's own offset is added inside the asm statement (glds16_at).
-template <int Q>
+template <int Q, bool NT>
 __device__ __forceinline__ void x6_load_piece(const Ctx6& c) {
   const int gt = c.g + kX6Slots - 2;
   const int g = gt < c.G ? gt : c.G - 1;
   const char* src = c.stream + ((unsigned)g * (unsigned)kX6StageBytes + (unsigned)(c.wave_s * kX6PiecesPerWave * 1024));
   const unsigned dst = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)c.lds +
                        (unsigned)(x6_slot(gt) * kX6StageBytes + c.wave_s * kX6PiecesPerWave * 1024);
-  glds16_at<Q * 1024>(src, (unsigned)c.lane * 16u, dst);
+  glds16_at<Q * 1024, NT>(src, (unsigned)c.lane * 16u, dst);
 }
 
 // the same with the piece number as a (constant-folded) value
+template <bool NT>
 __device__ __forceinline__ void x6_piece(const Ctx6& c, int q) {
   switch (q) {
-    case 0: x6_load_piece<0>(c); break;
-    case 1: x6_load_piece<1>(c); break;
-    case 2: x6_load_piece<2>(c); break;
-    case 3: x6_load_piece<3>(c); break;
-    case 4: x6_load_piece<4>(c); break;
-    case 5: x6_load_piece<5>(c); break;
-    case 6: x6_load_piece<6>(c); break;
-    case 7: x6_load_piece<7>(c); break;
-    case 8: x6_load_piece<8>(c); break;
-    case 9: x6_load_piece<9>(c); break;
-    case 10: x6_load_piece<10>(c); break;
-    default: x6_load_piece<11>(c); break;
+    case 0: x6_load_piece<0, NT>(c); break;
+    case 1: x6_load_piece<1, NT>(c); break;
+    case 2: x6_load_piece<2, NT>(c); break;
+    case 3: x6_load_piece<3, NT>(c); break;
+    case 4: x6_load_piece<4, NT>(c); break;
+    case 5: x6_load_piece<5, NT>(c); break;
+    case 6: x6_load_piece<6, NT>(c); break;
+    case 7: x6_load_piece<7, NT>(c); break;
+    case 8: x6_load_piece<8, NT>(c); break;
+    case 9: x6_load_piece<9, NT>(c); break;
+    case 10: x6_load_piece<10, NT>(c); break;
+    default: x6_load_piece<11, NT>(c); break;
   }
 }
 
@@ -198,10 +208,11 @@ __device__ __forceinline__ void x6_flush_mask(float* dst, unsigned* msk) {
 //          split anyway; the caller reads them again later and gets their four accumulator tiles back)
 //   LAST   the layer ends the weight stream: no LDS-DMA is issued during its last stage
 //   sav    training: stores the (activated) values of `src` into the save record as they pass (NoSave: inference)
-template <int NT, int NKS, int NKX, int KPS, bool RELU, bool KEEP, bool LAST, class Src, class Ext, class Sav = NoSave>
+template <int LID, int NT, int NKS, int NKX, int KPS, bool RELU, bool KEEP, bool LAST, class Src, class Ext, class Sav = NoSave>
 __device__ __forceinline__ void layer_x6(Ctx6& c, f32x16* out, const float* bias, const Src& src, const Ext& ext,
                                          float* keep = nullptr, const Sav& sav = Sav()) {
   constexpr int NK = NKS + NKX;
+  constexpr bool NTP = ((DMN_X6_NTMASK >> LID) & 1) != 0;      // this layer's DMA pieces are non-temporal
   constexpr int GPS = KPS * NT;                 // (k-step, tile) groups per full stage
   static_assert(GPS * 3 <= kX6StageChunks, "a stage holds three chunks per group");
 #pragma unroll
@@ -287,10 +298,10 @@ __device__ __forceinline__ void layer_x6(Ctx6& c, f32x16* out, const float* bias
       out[t] = P6::mfma(ah[ar], bh, out[t]);
 #endif
       if (dma) {
-        if (gi < kX6PiecesPerWave) x6_piece(c, gi);
+        if (gi < kX6PiecesPerWave) x6_piece<NTP>(c, gi);
         if (gi + 1 == groups) {                 // a short stage still owes the rest of its pieces
 #pragma unroll
-          for (int q = gi + 1; q < kX6PiecesPerWave; ++q) x6_piece(c, q);
+          for (int q = gi + 1; q < kX6PiecesPerWave; ++q) x6_piece<NTP>(c, q);
         }
       }
       if (ks + 1 < NK) {                        // the next k-step's operand fragments, a pair (or more) per tile
@@ -324,22 +335,23 @@ __device__ __forceinline__ bool x6_network(Ctx6& c, const float* cst, const floa
   const SrcTiles s_a{accA}, s_b{accB};
   constexpr int K8 = x6_ksteps_per_stage(8), K4 = x6_ksteps_per_stage(4);
 
+  const_section_ready();      // mlps.0 reads its bias before its first stage barrier
   // ---- mlps.0: position encoding (4 k-steps) -> A
-  layer_x6<8, 4, 0, K8, false, false, false>(c, accA, cst + kConstBias8 + h * 128, s_pe, s_pe);
+  layer_x6<0, 8, 4, 0, K8, false, false, false>(c, accA, cst + kConstBias8 + h * 128, s_pe, s_pe);
   // ---- mlps.1 .. mlps.4 in pairs A -> B -> A (rolled: a layer is ~2500 instructions); training: h_l = relu(mlps.(l-1))
   //      goes into the record while mlps.l consumes it
 #pragma unroll 1
   for (int l = 1; l < 5; l += 2) {
     if constexpr (SAVE) {
-      layer_x6<8, 16, 0, K8, true, false, false>(c, accB, cst + kConstBias8 + l * 256 + h * 128, s_a, s_pe, nullptr,
+      layer_x6<1, 8, 16, 0, K8, true, false, false>(c, accB, cst + kConstBias8 + l * 256 + h * 128, s_a, s_pe, nullptr,
                                                  SaveRows<true>{rec + save_h(l) * 64, msk});
       x6_flush_mask<4>(rec + save_mask(l) * 64, msk);
-      layer_x6<8, 16, 0, K8, true, false, false>(c, accA, cst + kConstBias8 + (l + 1) * 256 + h * 128, s_b, s_pe, nullptr,
+      layer_x6<1, 8, 16, 0, K8, true, false, false>(c, accA, cst + kConstBias8 + (l + 1) * 256 + h * 128, s_b, s_pe, nullptr,
                                                  SaveRows<true>{rec + save_h(l + 1) * 64, msk});
       x6_flush_mask<4>(rec + save_mask(l + 1) * 64, msk);
     } else {
-      layer_x6<8, 16, 0, K8, true, false, false>(c, accB, cst + kConstBias8 + l * 256 + h * 128, s_a, s_pe);
-      layer_x6<8, 16, 0, K8, true, false, false>(c, accA, cst + kConstBias8 + (l + 1) * 256 + h * 128, s_b, s_pe);
+      layer_x6<1, 8, 16, 0, K8, true, false, false>(c, accB, cst + kConstBias8 + l * 256 + h * 128, s_a, s_pe);
+      layer_x6<1, 8, 16, 0, K8, true, false, false>(c, accA, cst + kConstBias8 + (l + 1) * 256 + h * 128, s_b, s_pe);
     }
   }
   // ---- mlps.5 on cat([h, input_pts]) (skip connection, dm_nerf.py:86-87), mlps.6, mlps.7: A -> B -> A -> B
@@ -348,23 +360,23 @@ __device__ __forceinline__ bool x6_network(Ctx6& c, const float* cst, const floa
   // precomputes behind the loop, 324 of them, and parks in vector-register lanes: 580 v_writelane / v_readlane per pass)
   c.g = kX6StageL5;
   if constexpr (SAVE) {
-    layer_x6<8, 16, 4, K8, true, false, false>(c, accB, cst + kConstBias8 + 5 * 256 + h * 128, s_a, s_pe, nullptr,
+    layer_x6<2, 8, 16, 4, K8, true, false, false>(c, accB, cst + kConstBias8 + 5 * 256 + h * 128, s_a, s_pe, nullptr,
                                                SaveRows<true>{rec + save_h(5) * 64, msk});
     x6_flush_mask<4>(rec + save_mask(5) * 64, msk);
     c.g = kX6StageL6;
-    layer_x6<8, 16, 0, K8, true, false, false>(c, accA, cst + kConstBias8 + 6 * 256 + h * 128, s_b, s_pe, nullptr,
+    layer_x6<3, 8, 16, 0, K8, true, false, false>(c, accA, cst + kConstBias8 + 6 * 256 + h * 128, s_b, s_pe, nullptr,
                                                SaveRows<true>{rec + save_h(6) * 64, msk});
     x6_flush_mask<4>(rec + save_mask(6) * 64, msk);
     c.g = kX6StageL6 + 8;
-    layer_x6<8, 16, 0, K8, true, false, false>(c, accB, cst + kConstBias8 + 7 * 256 + h * 128, s_a, s_pe, nullptr,
+    layer_x6<4, 8, 16, 0, K8, true, false, false>(c, accB, cst + kConstBias8 + 7 * 256 + h * 128, s_a, s_pe, nullptr,
                                                SaveRows<true>{rec + save_h(7) * 64, msk});
     x6_flush_mask<4>(rec + save_mask(7) * 64, msk);
   } else {
-    layer_x6<8, 16, 4, K8, true, false, false>(c, accB, cst + kConstBias8 + 5 * 256 + h * 128, s_a, s_pe);
+    layer_x6<2, 8, 16, 4, K8, true, false, false>(c, accB, cst + kConstBias8 + 5 * 256 + h * 128, s_a, s_pe);
     c.g = kX6StageL6;
-    layer_x6<8, 16, 0, K8, true, false, false>(c, accA, cst + kConstBias8 + 6 * 256 + h * 128, s_b, s_pe);
+    layer_x6<3, 8, 16, 0, K8, true, false, false>(c, accA, cst + kConstBias8 + 6 * 256 + h * 128, s_b, s_pe);
     c.g = kX6StageL6 + 8;
-    layer_x6<8, 16, 0, K8, true, false, false>(c, accB, cst + kConstBias8 + 7 * 256 + h * 128, s_a, s_pe);
+    layer_x6<4, 8, 16, 0, K8, true, false, false>(c, accB, cst + kConstBias8 + 7 * 256 + h * 128, s_a, s_pe);
   }
 
   // ---- density_linear on h8 = relu(B) (dm_nerf.py:101): 256 -> 1 on the VALU.  (Taken while h8 passes through the
@@ -395,17 +407,17 @@ __device__ __forceinline__ bool x6_network(Ctx6& c, const float* cst, const floa
   f32x16 acc3[T];
   c.g = kX6StageRgbF;
   if constexpr (SAVE) {
-    layer_x6<8, 16, 0, K8, true, true, false>(c, accA, cst + kConstBias8 + 8 * 256 + h * 128, s_b, s_pe, h8,
+    layer_x6<5, 8, 16, 0, K8, true, true, false>(c, accA, cst + kConstBias8 + 8 * 256 + h * 128, s_b, s_pe, h8,
                                               SaveRows<true>{rec + save_h(8) * 64, msk});
     x6_flush_mask<4>(rec + save_mask(8) * 64, msk);
     // ---- rgb_feature_linears.0 on cat([feature, dirs]) -> 128, ReLU (dm_nerf.py:90-93); rgb_linear on the VALU (:102)
     c.g = kX6StageRgbH;
-    layer_x6<4, 16, 2, K4, false, false, false>(c, acc2, cst + kConstBias4 + h * 64, s_a, s_qe, nullptr,
+    layer_x6<6, 4, 16, 2, K4, false, false, false>(c, acc2, cst + kConstBias4 + h * 64, s_a, s_qe, nullptr,
                                                 SaveRows<false>{rec + kSaveFeat * 64, msk});
   } else {
-    layer_x6<8, 16, 0, K8, true, true, false>(c, accA, cst + kConstBias8 + 8 * 256 + h * 128, s_b, s_pe, h8);
+    layer_x6<5, 8, 16, 0, K8, true, true, false>(c, accA, cst + kConstBias8 + 8 * 256 + h * 128, s_b, s_pe, h8);
     c.g = kX6StageRgbH;
-    layer_x6<4, 16, 2, K4, false, false, false>(c, acc2, cst + kConstBias4 + h * 64, s_a, s_qe);
+    layer_x6<6, 4, 16, 2, K4, false, false, false>(c, acc2, cst + kConstBias4 + h * 64, s_a, s_qe);
   }
 #pragma unroll
   for (int i0 = 0; i0 < 64; i0 += 8) {         // eight values at a time: h8 and the view encoding stay in registers beside it
@@ -427,19 +439,19 @@ __device__ __forceinline__ bool x6_network(Ctx6& c, const float* cst, const floa
   // ---- ins_feature_linear on the same trunk output (h.detach(), dm_nerf.py:95-96), no activation -> A;
   //      ins_feature_linears.0 -> 128, ReLU (:97-99); ins_linear -> ins_num + 1 (:103)
   c.g = kX6StageInsF;
-  layer_x6<8, 16, 0, K8, false, false, false>(c, accA, cst + kConstBias8 + 9 * 256 + h * 128, s_h8, s_pe);
+  layer_x6<7, 8, 16, 0, K8, false, false, false>(c, accA, cst + kConstBias8 + 9 * 256 + h * 128, s_h8, s_pe);
   c.g = kX6StageInsH;
   if constexpr (SAVE) {
-    layer_x6<4, 16, 0, K4, false, false, false>(c, acc2, cst + kConstBias4 + 128 + h * 64, s_a, s_pe, nullptr,
+    layer_x6<8, 4, 16, 0, K4, false, false, false>(c, acc2, cst + kConstBias4 + 128 + h * 64, s_a, s_pe, nullptr,
                                                 SaveRows<false>{rec + kSaveInsF * 64, msk});
     c.g = kX6StageInsO;
-    layer_x6<T, 8, 0, x6_inso_ksteps_per_stage(T), true, false, true>(c, acc3, cst + kConstBiasO + h * 64, s_2, s_pe, nullptr,
+    layer_x6<9, T, 8, 0, x6_inso_ksteps_per_stage(T), true, false, true>(c, acc3, cst + kConstBiasO + h * 64, s_2, s_pe, nullptr,
                                                                      SaveRows<true>{rec + kSaveI1 * 64, msk});
     x6_flush_mask<2>(rec + kSaveMaskI1 * 64, msk);
   } else {
-    layer_x6<4, 16, 0, K4, false, false, false>(c, acc2, cst + kConstBias4 + 128 + h * 64, s_a, s_pe);
+    layer_x6<8, 4, 16, 0, K4, false, false, false>(c, acc2, cst + kConstBias4 + 128 + h * 64, s_a, s_pe);
     c.g = kX6StageInsO;
-    layer_x6<T, 8, 0, x6_inso_ksteps_per_stage(T), true, false, true>(c, acc3, cst + kConstBiasO + h * 64, s_2, s_pe);
+    layer_x6<9, T, 8, 0, x6_inso_ksteps_per_stage(T), true, false, true>(c, acc3, cst + kConstBiasO + h * 64, s_2, s_pe);
   }
 
 #pragma unroll

@@ -26,16 +26,32 @@ def pose_shard(n_poses: int, rank: int, world: int) -> List[int]:
 
 
 def gather_rays(local: torch.Tensor, n_rays: int, group=None) -> torch.Tensor:
-    """All-gather per-rank ray blocks (made with ``ray_shard``) back into ``[n_rays, ...]``."""
+    """All-gather per-rank ray blocks (made with ``ray_shard``) back into ``[n_rays, ...]``.  Equal blocks go through
+    ONE ``all_gather_into_tensor`` straight into the result (RCCL: one ring pass, no concatenation); ragged ones are
+    padded to the widest block.  Under the gloo backend (CPU tests, several ranks rehearsing on one GPU) device tensors
+    are staged through the host, which gloo's all-gather needs."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     sizes = [ray_shard(n_rays, r, world) for r in range(world)]
-    width = max(hi - lo for lo, hi in sizes)
-    padded = local.new_zeros((width,) + tuple(local.shape[1:]))
-    padded[: local.shape[0]] = local
-    parts = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(parts, padded, group=group)
-    return torch.cat([p[: hi - lo] for p, (lo, hi) in zip(parts, sizes)], 0)
+    lo, hi = sizes[dist.get_rank(group)]
+    if local.shape[0] != hi - lo:
+        raise ValueError(f"this rank owns rays [{lo}, {hi}) but was handed {local.shape[0]}")
+    staged = local.is_cuda and dist.get_backend(group) == "gloo"
+    src = local.cpu() if staged else local.contiguous()
+    if n_rays % world == 0:
+        out = src.new_empty((n_rays,) + tuple(src.shape[1:]))
+        if dist.get_backend(group) == "nccl":
+            dist.all_gather_into_tensor(out, src, group=group)
+        else:
+            dist.all_gather(list(out.chunk(world, 0)), src, group=group)
+    else:
+        width = max(b - a for a, b in sizes)
+        padded = src.new_zeros((width,) + tuple(src.shape[1:]))
+        padded[: src.shape[0]] = src
+        parts = [torch.empty_like(padded) for _ in range(world)]
+        dist.all_gather(parts, padded, group=group)
+        out = torch.cat([p[: b - a] for p, (a, b) in zip(parts, sizes)], 0)
+    return out.to(local.device) if staged else out
 
 
 def max_over_ranks(value: float, device, group=None) -> float:

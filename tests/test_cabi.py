@@ -84,23 +84,36 @@ def test_product_package_never_imports_the_oracle():
 
 
 def test_inline_asm_accumulator_reads_keep_their_distance_from_the_producing_mfma(tmp_path):
-    """field_x3.h reads finished accumulator tiles with inline asm (v_accvgpr_read_b32) so that they stay in their
-    AGPRs; the compiler inserts no MFMA -> VALU hazard wait states for inline asm, so the distance is guaranteed by
-    construction (one full k-step on the other tile) and checked here on the generated ISA."""
+    """field_x3.h / field_x6.h read finished accumulator tiles with inline asm (v_accvgpr_read_b32) so that they stay in
+    their AGPRs; the compiler inserts no MFMA -> VALU hazard wait states for inline asm, so the distance is guaranteed
+    by construction (x3: one full k-step on the other tile; x6: 6 x (NT - 1) MFMAs) and checked here on the generated
+    ISA of every kernel that does it -- the default (bf16x6) field kernel and the fused kernel included.  The x6 field
+    kernels must also stay lean: no scratch, no SGPRs parked in vector-register lanes (tools/check_acc_hazard.py)."""
     import shutil
     import subprocess
     import sys
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     from dm_nerf_amd.build import FLAGS
     flags = [f for f in FLAGS if f not in ("-shared", "-fPIC")]
-    for src in ("field_bwd_x3.hip", "field_fwd_x3.hip"):
+    sources = {"field_bwd_x3.hip": [], "field_fwd_x3.hip": [], "field_fwd_x6.hip": ["--lean", "field_fwd_x6_kernel"],
+               "field_fused_x3.hip": []}
+
+    def check(src):
         out = str(tmp_path / (src + ".s"))
         subprocess.run([hipcc, *flags, "-S", "--cuda-device-only", "-o", out,
                         os.path.join(root, "dm_nerf_amd", "csrc", src)], check=True, capture_output=True)
-        res = subprocess.run([sys.executable, os.path.join(root, "tools", "check_acc_hazard.py"), out],
-                             capture_output=True, text=True)
-        assert res.returncode == 0, res.stdout + res.stderr
+        return subprocess.run([sys.executable, os.path.join(root, "tools", "check_acc_hazard.py"), out, *sources[src]],
+                              capture_output=True, text=True)
+
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        results = dict(zip(sources, pool.map(check, sources)))
+    for src, res in results.items():
+        assert res.returncode == 0, src + "\n" + res.stdout + res.stderr
         assert "accumulator reads" in res.stdout
+    # every instantiation of the default kernel was seen (4 head widths x inference / saving), and of the fused x6 network
+    assert results["field_fwd_x6.hip"].stdout.count("field_fwd_x6_kernel") == 8
+    assert results["field_fused_x3.hip"].stdout.count("NetX6") == 4

@@ -58,9 +58,11 @@ def _worker(rank, world, port, result_path):
         lo, hi = ray_shard(H * W, rank, world)
         local = _render_block(lo, hi)
         full = gather_rays(local, H * W)
+        a, b = ray_shard(7, rank, world)                      # ragged blocks (4 + 3 rays): the padded path
+        ragged = gather_rays(torch.arange(a, b, dtype=torch.float32).reshape(-1, 1) * 2.0, 7)
         slowest = max_over_ranks(float(rank + 1), torch.device("cpu"))
         if rank == 0:
-            np.savez(result_path, full=full.numpy(), slowest=slowest)
+            np.savez(result_path, full=full.numpy(), slowest=slowest, ragged=ragged.numpy())
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -78,6 +80,7 @@ def test_two_rank_sharded_render_equals_single_rank(tmp_path):
     np.testing.assert_array_equal(got["full"][:, 0], np.arange(H * W, dtype=np.float32))   # placement exact
     np.testing.assert_allclose(got["full"][:, 1:], want[:, 1:], rtol=0, atol=1e-5)
     assert float(got["slowest"]) == 2.0
+    np.testing.assert_array_equal(got["ragged"][:, 0], 2.0 * np.arange(7, dtype=np.float32))
 
 
 def _grad_worker(rank, world, port, result_path):
@@ -177,3 +180,49 @@ def test_sharded_statistics_give_the_unsharded_loss_and_gradient(tmp_path):
     # the matched term is replicated, the mean term is a share: loss_0 + loss_1 - matched = whole-batch loss
     matched = loss - (net(x) ** 2).mean()
     torch.testing.assert_close(r0["loss"] + r1["loss"] - matched.detach(), loss.detach(), rtol=1e-5, atol=1e-7)
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did(tmp_path):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: the parent starts N ranks under
+    torch.distributed.run BEFORE importing torch and exits with their status (dm_nerf_amd/launch.py).  The probe script
+    runs that exact prologue with gloo ranks on the CPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    probe = os.path.join(root, "tests", "spawn_probe.py")
+    res = subprocess.run([sys.executable, probe, "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    got = json.loads(lines[0])
+    assert got == {"n_gpus": 2, "sum_of_ranks_plus_one": 3.0, "master_addr": "127.0.0.1"}
+    # a failing rank is the parent's exit status, not a hang and not rc 0
+    res = subprocess.run([sys.executable, probe, "--gpus=2", "--fail-on-rank", "1"], env=env, capture_output=True, text=True,
+                         timeout=300)
+    assert res.returncode != 0
+    # one rank needs no launcher
+    res = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and json.loads(res.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+    # bench.py and tools/bench_train.py run the same prologue before they import torch
+    for script in ("bench.py", os.path.join("tools", "bench_train.py")):
+        src = open(os.path.join(root, script)).read()
+        assert "_self_launch_if_needed()" in src
+        assert src.index("_self_launch_if_needed()\n\n") < src.index("\nimport torch"), script
+
+
+def test_launch_helpers():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("_dmn_launch", os.path.join(root, "dm_nerf_amd", "launch.py"))
+    launch = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(launch)
+    assert launch.requested_gpus(["--steps", "3"]) == 1
+    assert launch.requested_gpus(["--gpus", "4", "--steps", "3"]) == 4 and launch.requested_gpus(["--gpus=8"]) == 8
+    assert launch.needs_self_launch(["--gpus", "2"], environ={})
+    assert not launch.needs_self_launch(["--gpus", "2"], environ={"WORLD_SIZE": "2", "RANK": "0"})
+    assert not launch.needs_self_launch(["--gpus", "1"], environ={})
+    cmd = launch.launcher_command("bench.py", ["--gpus", "2", "--steps", "1"], 2, port=29512)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=2" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-5:] == ["bench.py", "--gpus", "2", "--steps", "1"]

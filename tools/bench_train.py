@@ -3,7 +3,7 @@
 Not the headline bench (bench.py is).
 
     python tools/bench_train.py [--rays 4096 --steps 5 --precision bf16x6|fp32|bf16x3 --instance --penalize]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/bench_train.py --gpus N
+    python tools/bench_train.py --gpus N        (starts its own N ranks; or under torch.distributed.run --nproc-per-node N)
 
 With N ranks the rays of a step are sharded (strong scaling: --rays is the global batch), every rank runs forward and
 the hand-written backward on its shard, the loss heads all-reduce their batch statistics (a few hundred bytes:
@@ -16,10 +16,25 @@ import os
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+
+
+def _self_launch_if_needed():
+    """`--gpus N` without a launcher: start N ranks under torch.distributed.run as a child process (before torch is
+    imported: the parent never touches the GPU) and exit with its status; dm_nerf_amd/launch.py, loaded by path."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_dmn_launch", os.path.join(ROOT, "dm_nerf_amd", "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if mod.needs_self_launch(sys.argv[1:]):
+        sys.exit(mod.self_launch(os.path.abspath(__file__), sys.argv[1:]))
+
+
+if __name__ == "__main__":
+    _self_launch_if_needed()
+
+import torch  # noqa: E402
 import dm_nerf_amd as dm  # noqa: E402
 from dm_nerf_amd import parallel, synthetic, trainer  # noqa: E402
 

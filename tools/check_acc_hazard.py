@@ -1,26 +1,70 @@
 #!/usr/bin/env python3
-"""Static check of the x3 kernels' ISA: every v_accvgpr_read of an accumulator register must be separated from the
-last MFMA that wrote its tuple by >= 11 wait states (instructions count 1, s_nop N counts N + 1) -- the inline-asm
-reads of field_x3.h are not covered by the compiler's hazard recognizer.
-    hipcc ... -S --cuda-device-only -o x.s field_fwd_x3.hip && python tools/check_acc_hazard.py x.s"""
+"""Static check of the split-precision kernels' ISA (x3, x6 and the fused kernel's instantiations of both).
+
+1. Every v_accvgpr_read of an accumulator register must be separated from the last MFMA that wrote its tuple by >= 11
+   wait states (instructions count 1, s_nop N counts N + 1, an MFMA in between 8) -- the inline-asm reads of field_x3.h /
+   field_x6.h are not covered by the compiler's hazard recognizer.  Rolled loops are walked twice (every backward branch
+   is followed once), so a read at the top of a loop body is also held against the MFMAs at its bottom.
+2. --lean KERNEL_SUBSTRING (repeatable): kernels whose name contains it must have no scratch
+   (.amdhsa_private_segment_fixed_size 0) and no v_writelane / v_readlane SGPR parking (the 580-writelane regression of
+   experiments/README.md, "Compiler notes").
+
+    hipcc ... -S --cuda-device-only -o x.s field_fwd_x6.hip && python tools/check_acc_hazard.py x.s --lean x6_kernel"""
 import re
 import sys
 
-lines = open(sys.argv[1]).read().split('\n')
-starts = [i for i, l in enumerate(lines) if l.startswith('_Z') and 'x3_kernel' in l]
-worst_all = None
-for i0 in starts:
-    body = []
-    for l in lines[i0 + 1:]:
-        s = l.strip()
-        if s.startswith('.Lfunc_end'):
-            break
-        if s and not s.startswith((';', '.')) and not s.split()[0].endswith(':'):
-            body.append(s)
-    last = {}
-    worst = 10 ** 9
-    reads = 0
-    for j, l in enumerate(body):
+KERNEL_TAGS = ("x3_kernel", "x6_kernel", "x6w_kernel")
+MIN_WAIT_STATES = 11
+
+
+def kernel_bodies(lines):
+    """name -> list of (label or None, instruction text) of every kernel whose name carries one of KERNEL_TAGS."""
+    out = {}
+    starts = [i for i, l in enumerate(lines) if re.match(r'_Z\S+:', l) and any(t in l for t in KERNEL_TAGS)]
+    for i0 in starts:
+        body, label = [], None
+        for l in lines[i0 + 1:]:
+            s = l.strip()
+            if s.startswith('.Lfunc_end'):
+                break
+            if not s or s.startswith(';'):
+                continue
+            if s.split()[0].endswith(':'):
+                label = s.split()[0][:-1]
+                continue
+            if s.startswith('.'):
+                continue
+            body.append((label, s))
+            label = None
+        out[lines[i0].split(':')[0]] = body
+    return out
+
+
+def walk(body):
+    """Instruction order with every backward branch followed once."""
+    where = {lab: j for j, (lab, _) in enumerate(body) if lab}
+    taken, order, j = set(), [], 0
+    while j < len(body):
+        ins = body[j][1]
+        order.append(ins)
+        m = re.match(r's_(?:c)?branch\S*\s+(\S+)', ins)
+        if m and m.group(1) in where and where[m.group(1)] <= j and j not in taken:
+            taken.add(j)
+            j = where[m.group(1)]
+            continue
+        j += 1
+    return order
+
+
+def wait_states(ins):
+    if ins.startswith('s_nop'):
+        return int(ins.split()[1]) + 1
+    return 8 if ins.startswith('v_mfma') else 1
+
+
+def check_reads(order):
+    last, worst, reads = {}, 10 ** 9, 0
+    for j, l in enumerate(order):
         m = re.match(r'v_mfma\S* a\[(\d+):(\d+)\]', l)
         if m:
             last[(int(m.group(1)), int(m.group(2)))] = j
@@ -31,11 +75,44 @@ for i0 in starts:
             for (lo, hi), jw in last.items():
                 if lo <= a <= hi:
                     reads += 1
-                    ws = sum((int(x.split()[1]) + 1) if x.startswith('s_nop') else (8 if x.startswith('v_mfma') else 1)
-                             for x in body[jw + 1:j])
+                    ws = 0
+                    for x in order[jw + 1:j]:
+                        ws += wait_states(x)
+                        if ws >= 4096:          # far enough: do not sum kernel-long stretches for every read
+                            break
                     worst = min(worst, ws)
-    if reads == 0:
-        continue
-    print(f"{lines[i0][:100]}  accumulator reads {reads}, fewest wait states after the producing MFMA: {worst}")
-    worst_all = worst if worst_all is None else min(worst_all, worst)
-sys.exit(0 if worst_all is not None and worst_all >= 11 else 1)
+    return reads, worst
+
+
+def scratch_sizes(lines):
+    out, name = {}, None
+    for l in lines:
+        s = l.strip()
+        if s.startswith('.amdhsa_kernel '):
+            name = s.split()[1]
+        elif s.startswith('.amdhsa_private_segment_fixed_size') and name:
+            out[name] = int(s.split()[1])
+    return out
+
+
+def main(argv):
+    path, lean = argv[1], [argv[i + 1] for i, a in enumerate(argv) if a == '--lean']
+    lines = open(path).read().split('\n')
+    bodies, scratch = kernel_bodies(lines), scratch_sizes(lines)
+    worst_all, ok = None, True
+    for name, body in bodies.items():
+        reads, worst = check_reads(walk(body))
+        lanes = sum(1 for _, s in body if s.startswith(('v_writelane', 'v_readlane')))
+        if reads:
+            print(f"{name[:100]}  accumulator reads {reads}, fewest wait states after the producing MFMA: {worst}; "
+                  f"scratch {scratch.get(name, '?')} B, v_writelane/v_readlane {lanes}")
+            worst_all = worst if worst_all is None else min(worst_all, worst)
+        if any(t in name for t in lean):
+            if scratch.get(name) != 0 or lanes != 0:
+                print(f"NOT LEAN: {name[:100]}: scratch {scratch.get(name)} B, v_writelane/v_readlane {lanes}")
+                ok = False
+    return 0 if ok and worst_all is not None and worst_all >= MIN_WAIT_STATES else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv))

@@ -145,6 +145,14 @@ def study_c2w() -> np.ndarray:
     return c2w
 
 
+def flip_ray_sets():
+    """G13: the ray sets of the end-to-end gates, as (image side, flat pixel indices) of the square study camera:
+    the 2048 random pixels of the 800x800 image (tests/test_gpu_parity.py, flip-rate tests) and the 1024 pixels of the
+    64x64 image smoke() renders (every fourth)."""
+    return {"t2048": (800, np.sort(np.random.default_rng(31).choice(800 * 800, size=2048, replace=False))),
+            "s1024": (64, np.arange(0, 64 * 64, 4)[:1024])}
+
+
 def path_rays(n_rays: int, seed: int = 16):
     """Random subset of the 800x800 'study' camera's rays (computed in float64 -> fp32 here so
     that ray generation is not part of this case)."""

@@ -358,10 +358,60 @@ def g12_manipulator():
     save("g12_manipulator.npz", **out)
 
 
+def _reference_maps(rays, dtype):
+    """One deterministic dm_nerf call of the reference (networks/render.py:31-96) in `dtype`: the modules, the rays and
+    every tensor the reference creates on the way (lattice, linspace draws, the 1e10 sentinel) are of that type; the
+    parameters are the same fp32 values (load_state_dict copies them into the modules exactly)."""
+    keep = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        pos_enc, dir_enc, coarse, fine = build_nets(13, 0, 1)
+        assert next(coarse.parameters()).dtype == dtype
+        n = rays.shape[1]
+        z = ref_helpers.z_val_sample(n, cases.NEAR, cases.FAR, cases.N_SAMPLES).to(dtype)
+        args = SimpleNamespace(perturb=0.0, N_importance=cases.N_IMPORTANCE, is_train=False, N_ins=None)
+        with torch.no_grad():
+            res = ref_render.dm_nerf(rays.to(dtype), pos_enc, dir_enc, coarse, fine, z, args)
+        assert res["rgb_fine"].dtype == dtype and res["z_vals_fine"].dtype == dtype, (res["rgb_fine"].dtype, dtype)
+        return {k: res[k] for k in ("rgb_fine", "depth_fine", "ins_fine", "z_vals_fine", "rgb_coarse", "depth_coarse")}
+    finally:
+        torch.set_default_dtype(keep)
+
+
+def g13_flip():
+    """The reference against ITSELF behind the sampler (networks/helpers.py:139-153, networks/render.py:66-70): the same
+    deterministic dm_nerf call in fp32 and in fp64 (fp64 modules holding the same fp32 parameters) on the ray sets the
+    end-to-end gates use -- the 2048 random pixels of the 800x800 study camera (tests/test_gpu_parity.py,
+    test_flip_rate_*) and the 1024 rays of smoke()'s 64x64 camera.  Stored: the rays (the reference's get_rays_k on the
+    CPU, so that both sides start from the same bits), the fp32 maps and merged depths, the fp64 maps, and the
+    per-ray deviation of the reference's fp32 result from its fp64 result."""
+    out = {}
+    for tag, (hw, pick) in cases.flip_ray_sets().items():
+        K, c2w = cases.study_intrinsics(hw, hw), cases.study_c2w()
+        ro, rd = ref_helpers.get_rays_k(hw, hw, K, torch.Tensor(c2w))
+        rays = torch.stack([ro.reshape(-1, 3).float()[pick], rd.reshape(-1, 3).float()[pick]], 0)
+        r32 = _reference_maps(rays, torch.float32)
+        r64 = _reference_maps(rays, torch.float64)
+        out[f"{tag}_rays"] = rays
+        out[f"{tag}_pick"] = np.asarray(pick, np.int32)
+        for k in ("rgb_fine", "depth_fine", "ins_fine", "z_vals_fine", "rgb_coarse", "depth_coarse"):
+            out[f"{tag}_{k}"] = r32[k]
+        for k in ("rgb_fine", "depth_fine", "ins_fine"):
+            out[f"{tag}_f64_{k}"] = r64[k].float()
+            a, b = r32[k].double().reshape(rays.shape[1], -1), r64[k].reshape(rays.shape[1], -1)
+            per_ray = (a - b).abs().max(-1).values / b.abs().max()
+            out[f"{tag}_self_dev_{k}"] = per_ray.float()
+            print(f"  {tag} {k}: reference fp32 vs fp64: {float((per_ray > 1e-4).double().mean()):.4f} of {rays.shape[1]} rays "
+                  f"beyond 1e-4, worst {float(per_ray.max()):.2e}")
+        dz = (r32["z_vals_fine"].double() - r64["z_vals_fine"]).abs().max(-1).values / r64["z_vals_fine"].abs().max()
+        out[f"{tag}_self_dev_z_vals_fine"] = dz.float()
+    save("g13_flip.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     table = {"g1": g1_rays, "g2": g2_encode, "g3": g3_field, "g4": g4_composite, "g5": g5_sampler,
              "g6": g6_path, "g7": g7_gradients, "g8": g8_image, "g9": g9_selectors, "g10": g10_penalizer,
-             "g11": g11_criterion, "g12": g12_manipulator}
+             "g11": g11_criterion, "g12": g12_manipulator, "g13": g13_flip}
     for key in which:
         table[key]()

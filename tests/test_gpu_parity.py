@@ -489,39 +489,46 @@ def test_replica_shape_config():
     assert rel_err(H(got["rgb_coarse"]), want["rgb_coarse"].numpy()) < 1e-4
 
 
-# ---- end-to-end deviation on a sample large enough to measure the sampler's flip RATE ---------------------------------
-# Observed on MI355X (this test's print, and bench.py's `deviation_vs_cpu_oracle` on 16384 rays): the fraction of rays
-# whose fine outputs leave 1e-4 is the same in all three arithmetics -- it is the rate at which the reference's sampler
-# flips on 1e-7 noise, not a property of the field kernel's precision.  Caps = 2x the observed rate.
-# observed (2048 random pixels of the 800x800 image): fp32 0.0117 / 0.0132, fp16x3 0.0093 / 0.0117, bf16x3 0.0112 / 0.0142
-_FLIP_CAPS = {"fp32": (0.0235, 0.0265), "fp16x3": (0.0190, 0.0235), "bf16x3": (0.0225, 0.0285),     # (rgb_fine, depth_fine)
-              "bf16x6": (0.0235, 0.0265)}                                       # held to the exact kernel's caps
+# ---- end-to-end deviation behind the sampler, pinned to the REFERENCE's own behaviour (G13) ----------------------------
+# The reference is not 1e-4-reproducible against itself behind sample_pdf (networks/helpers.py:139-153): run in fp64 on
+# the same rays (same fp32 parameters) it moves ~1 % of them beyond 1e-4 -- `denom < 1e-5 -> 1` and the searchsorted
+# bins make a resampled depth jump by a bin width on 1e-7 noise.  tests/golden/g13_flip.npz holds, for the 2048 random
+# pixels of the 800x800 study camera and for smoke()'s 1024 rays: the rays, the reference's fp32 maps and merged depths,
+# its fp64 maps, and its own per-ray fp32-vs-fp64 deviation.  Gates (every arithmetic):
+#   (i)   the fraction of rays whose HIP fine outputs leave 1e-4 of the reference's fp64 result is at most 1.5x the
+#         fraction of the reference's own fp32 result that does (same rays, same yardstick);
+#   (ii)  attribution, 100 % of the rays: every ray beyond 1e-4 of the reference's fp32 maps has a merged depth that
+#         differs from the reference's by more than 1e-4 -- a sampler flip -- and every ray, flipped or not, is within
+#         1e-4 once the HIP fine stage is fed the reference's merged depths.
+# Against the reference's fp32 maps themselves two independent flip sources add up (the reference's fp32 noise and
+# ours): that fraction is reported and held to 2 x 1.5x the reference's own.
+from flipgate import FLIP_KEYS as _FLIP_KEYS, flip_gate  # noqa: E402  (tests/golden/flipgate.py; smoke() runs the same gate)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "fp16x3", "bf16x3", "bf16x6"])
-def test_flip_rate_against_oracle_on_2048_rays(precision):
-    Hh = W = 800
-    n = 2048
+def _flip_outputs(g, tag, precision):
     pos, view, coarse, fine, args = nets(13, 0, 1)
     args.precision = precision
-    K, c2w = oracle.dmsr_intrinsics(Hh, W), oracle.study_pose(0)
-    pick = torch.from_numpy(np.sort(np.random.default_rng(31).choice(Hh * W, size=n, replace=False)))
-    ro, rd = dm.get_rays_k(Hh, W, K, c2w)
-    rays = torch.stack([ro.reshape(-1, 3)[pick.to(DEV)], rd.reshape(-1, 3)[pick.to(DEV)]], 0)
+    rays = G(g[f"{tag}_rays"])
+    n = rays.shape[1]
     z = dm.z_val_sample(n, args.near, args.far, 64)
     with torch.no_grad():
-        got = dm.dm_nerf(rays, pos, view, coarse, fine, z, args)
-        want = oracle.render_rays(rays.cpu(), oracle.make_params(13, 0), oracle.make_params(13, 1),
-                                  oracle.coarse_depths(n, args.near, args.far, 64))
-    seen = {k: (_rays_off(H(got[k]), want[k].numpy()), rel_err(H(got[k]), want[k].numpy()))
-            for k in ("rgb_fine", "depth_fine", "ins_fine", "rgb_coarse", "depth_coarse", "ins_coarse")}
-    print(f"{precision}: (fraction of rays > 1e-4, worst) {seen}")
-    for k in ("rgb_coarse", "depth_coarse", "ins_coarse"):             # in front of the sampler: 1e-4 outright
-        assert seen[k][1] < 1e-4, (k, seen[k])
-    cap_rgb, cap_depth = _FLIP_CAPS[precision]
-    assert seen["rgb_fine"][0] <= cap_rgb and seen["depth_fine"][0] <= cap_depth, seen
-    assert seen["ins_fine"][0] <= 0.002, seen                           # the instance map is smooth in the depths
-    assert seen["rgb_fine"][1] < 2.1e-3 and seen["depth_fine"][1] < 3.1e-3   # 2x the observed worst (1.05e-3, 1.54e-3)
+        out = dm.dm_nerf(rays, pos, view, coarse, fine, z, args)
+        z_ref = G(g[f"{tag}_z_vals_fine"])
+        raw = ops.field_rays(rays[0], rays[1], z_ref, fine.blob(precision), 13, precision)
+        rgb, _, depth, ins = dm.render_train(raw, z_ref, rays[1])
+    got = {k: H(out[k]) for k in _FLIP_KEYS + ("z_vals_fine", "rgb_coarse", "depth_coarse")}
+    return got, {"rgb_fine": H(rgb), "depth_fine": H(depth), "ins_fine": H(ins)}
+
+
+@pytest.mark.parametrize("tag", ["t2048", "s1024"])
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3", "bf16x3", "bf16x6"])
+def test_flip_rate_is_the_references_own_and_every_flip_is_a_sampler_flip(golden, precision, tag):
+    g = golden("g13_flip.npz")
+    got, staged = _flip_outputs(g, tag, precision)
+    for k in ("rgb_coarse", "depth_coarse"):                          # in front of the sampler: 1e-4 outright
+        assert rel_err(got[k], g[f"{tag}_{k}"]) < 1e-4, k
+    report = flip_gate(got, g, tag, precision, staged)
+    print(f"{precision} {tag}: {report}")
 
 
 # ---- BASELINE config 5: ScanNet full-resolution render_path with the loader's crop mask, image-sharded ----------

@@ -108,8 +108,8 @@ def synthetic_scene(device, near=4.0, far=15.0):
 def training_leg(nerf, K, pose, device, n_rays: int = 4096, steps: int = 4):
     """BASELINE config 4 on one GPU, outside the timed region: `steps` optimisation steps of `n_rays` random rays of
     the same camera (stochastic path, colour + instance-matching + emptiness losses, Adam), hand-written forward and
-    backward kernels, with the bf16x6 forward (fp32-grade products on the bf16 pipe), the exact-fp32 forward and the bf16x3
-    forward."""
+    backward kernels: forward AND backward in bf16x6 (fp32-grade products on the bf16 pipe both ways: the config-4
+    number), in exact fp32 MFMA, and -- the explicit opt-in -- in bf16x3 (16 operand bits)."""
     from dm_nerf_amd import trainer
     pos, view, coarse, fine, args = nerf
     state = [{k: v.clone() for k, v in m.state_dict().items()} for m in (coarse, fine)]
@@ -124,7 +124,8 @@ def training_leg(nerf, K, pose, device, n_rays: int = 4096, steps: int = 4):
     result = {"rays_per_step": n_rays, "losses": "mse + ins_criterion + ins_penalizer (coarse and fine), Adam 5e-4; the "
               "Hungarian step of ins_criterion runs as a kernel (assign='device': scipy's algorithm in fp64, bit-identical "
               "matching, tests/test_gpu_parity.py) so that the step never waits for the device",
-              "backward": "HIP: backward-data + weight-gradient kernels (bf16x3), compositing backward"}
+              "backward": "HIP: backward-data + weight-gradient kernels in the arithmetic of the forward's grade "
+                          "(ops.backward_precision: bf16x6 -> bf16x6, fp32 -> exact fp32 MFMA, bf16x3 -> bf16x3), compositing backward"}
     coarse.train(); fine.train()
     for prec in ("bf16x6", "fp32", "bf16x3"):
         targs.precision = prec
@@ -143,7 +144,8 @@ def training_leg(nerf, K, pose, device, n_rays: int = 4096, steps: int = 4):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         prof, ops.PROFILE = ops.PROFILE, None
-        entry = {"ms_per_step": dt * 1e3, "rays_per_s": n_rays / dt, "loss_total": last["total"], "kernels_ms_per_step": {}}
+        entry = {"ms_per_step": dt * 1e3, "rays_per_s": n_rays / dt, "loss_total": last["total"],
+                 "backward_precision": ops.backward_precision(prec), "kernels_ms_per_step": {}}
         for name in ("field_fwd_save", "field_bwd_data", "field_bwd_weights"):
             _, secs, _ = kernel_stats(prof, name)
             entry["kernels_ms_per_step"][name] = secs / steps * 1e3

@@ -70,6 +70,11 @@ SIGNATURES = {
     "dmn_field_bwd_pack_index_x3_len": (c_long, [c_int]),
     "dmn_field_bwd_pack_index_x3": (c_int, [c_int, _P]),
     "dmn_field_bwd_data_x3": (c_int, [_P, _P, _P, c_long, c_int, _P, _P]),
+    "dmn_field_bwd_blob_x6_bytes": (c_long, [c_int]),
+    "dmn_field_bwd_pack_index_x6_len": (c_long, [c_int]),
+    "dmn_field_bwd_pack_index_x6": (c_int, [c_int, _P]),
+    "dmn_field_pack_x6_n": (c_int, [_P, _P, c_long, _P, _P]),
+    "dmn_field_bwd_data_x6": (c_int, [_P, _P, _P, c_long, c_int, _P, _P]),
     "dmn_field_pack_x3_n": (c_int, [_P, _P, c_long, c_int, _P, _P]),
     "dmn_field_wgrad_index_len": (c_long, [c_int]),
     "dmn_field_wgrad_index": (c_int, [c_int, _P]),

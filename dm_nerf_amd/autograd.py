@@ -4,10 +4,11 @@ Forward of both functions is the hand-written HIP kernel.  Backward:
 
 * ``CompositeFn``: hand-written HIP kernel (``dmn_composite_bwd``) with the reference's detach topology
   (the instance map is composited with ``weights.detach()``, networks/render.py:22-23).
-* ``FieldFn``: hand-written HIP kernels (``csrc/field_bwd.hip``): the forward writes a save record, a fused
-  backward-data kernel chains dL/d pre-activation through the layers in registers, a split-K MFMA kernel reduces
-  the 30 weight/bias gradients over all sample points.  ``args.precision`` selects the forward under autograd:
-  exact fp32, or three bf16 MFMAs per product for "bf16x3" / "fp16x3".
+* ``FieldFn``: hand-written HIP kernels (``csrc/field_bwd*.hip``): the forward writes a save record, a fused
+  backward-data kernel chains dL/d pre-activation through the layers in registers, split-K MFMA kernels reduce
+  the 30 weight/bias gradients over all sample points.  ``args.precision`` selects the arithmetic of forward AND
+  backward under autograd: "bf16x6" (default; fp32-grade on the bf16 pipe) and "fp32" (exact fp32 MFMA) train with
+  fp32-grade gradients, "bf16x3" / "fp16x3" (opt-in) with three bf16 MFMAs per product.
   Nothing here runs on the CPU; the library-GEMM cross-check of these kernels lives with the tests
   (``tests/library_backward.py``).
 
@@ -24,9 +25,14 @@ from ._lib import check, current_stream, load, ptr
 
 
 class FieldFn(torch.autograd.Function):
-    """raw = field(rays, z; params), hand-written HIP both ways: the exact-fp32 forward kernel also writes its save
-    record; backward = backward-data kernel (dL/d pre-activation of every layer, chained in registers) + split-K
-    weight-gradient kernel + scatter into the flat gradient (``ops.field_backward``)."""
+    """raw = field(rays, z; params), hand-written HIP both ways.  Forward: the saving variant of the field kernel of
+    ``precision`` -- "bf16x6" (the default: fp32 operands as exact three-way bf16 splits, six MFMA products per
+    product), "fp32" (exact fp32 MFMA), or the two-way split "bf16x3" ("fp16x3" trains in bf16x3) -- which also writes
+    the save record.  Backward = backward-data kernel (dL/d pre-activation of every layer, chained in registers) +
+    split-K weight-gradient kernels + scatter into the flat gradient (``ops.field_backward``), in the arithmetic
+    ``ops.backward_precision(precision)`` gives: fp32-grade for the fp32-grade forwards (the reference back-propagates
+    in fp32, train_dmsr.py:62-64), bf16x3 only for the bf16x3 forward.  ``BACKWARD_OVERRIDE`` (module level; a pair
+    (data, weights) of "fp32" | "bf16x6" | "bf16x3") replaces that choice for experiments and A/B timing."""
 
     @staticmethod
     def forward(ctx, rays_o, rays_d, z, model, precision, *params):
@@ -34,6 +40,7 @@ class FieldFn(torch.autograd.Function):
         fwd = precision if precision in ("fp32", "bf16x6") else "bf16x3"
         raw, save = ops.field_rays_save(rays_o, rays_d, z, model.blob(fwd), model.ins_num, fwd)
         ctx.save, ctx.model = save, model
+        ctx.backward_precisions = BACKWARD_OVERRIDE or (ops.backward_precision(fwd),) * 2
         ctx.meta = [(p.shape, p.numel(), p.requires_grad) for p in params]
         return raw
 
@@ -45,9 +52,10 @@ class FieldFn(torch.autograd.Function):
                                "(retain_graph=True) is not supported -- run the forward again")
         model = ctx.model
         n_params = sum(n for _, n, _ in ctx.meta)
-        blob = model.blob("bwd" if DATA_PRECISION == "fp32" else "bwd_x3")
-        flat = ops.field_backward(g_raw, ctx.save, blob, model.ins_num, model.wgrad_index(), n_params,
-                                  wgrad_precision=WGRAD_PRECISION, data_precision=DATA_PRECISION,
+        data_precision, wgrad_precision = ctx.backward_precisions
+        flat = ops.field_backward(g_raw, ctx.save, model.blob(ops.BWD_BLOB[data_precision]), model.ins_num,
+                                  model.wgrad_index(), n_params, wgrad_precision=wgrad_precision,
+                                  data_precision=data_precision,
                                   out=model.lend_grad_buffer())  # a GradBucket's slice when one was adopted and is free
         ctx.save = None
         out: List = []
@@ -58,8 +66,7 @@ class FieldFn(torch.autograd.Function):
         return (None, None, None, None, None, *out)
 
 
-DATA_PRECISION = "bf16x3"       # backward-data chain: "bf16x3" or "fp32" (exact MFMA); masks come from the save record
-WGRAD_PRECISION = "bf16x3"      # weight-gradient GEMMs: "bf16x3" (three bf16 MFMAs per product) or "fp32" (exact MFMA)
+BACKWARD_OVERRIDE = None        # None: ops.backward_precision(forward); else (data_precision, wgrad_precision)
 
 
 class CompositeFn(torch.autograd.Function):

@@ -312,14 +312,16 @@ __global__ __launch_bounds__(256, 1) void field_wgrad_kernel(const WgArgs a) {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-template <int OT, int KT, int WR, int WC>
+// X6: three planes (hi, mid, lo: exact three-way splits) and six products, as the ring kernel below.
+template <int OT, int KT, int WR, int WC, bool X6>
 __global__ __launch_bounds__(256, 1) void field_wgrad_x3_kernel(const WgArgs a) {
   constexpr int R = 32 * (OT + KT);
   constexpr int RB = 80;                   // bytes per LDS row: 32 bf16 + 16 pad (16-byte reads of 16 lanes hit 64 banks)
   constexpr int NP = OT + KT;
   constexpr int OTW = OT / WR, KTW = KT / WC;
   static_assert(WR * WC == 4 && OTW * WR == OT && KTW * WC == KT && OTW * KTW <= 16, "wave grid");
-  __shared__ __attribute__((aligned(16))) char lds[2 * R * RB];   // hi plane, lo plane
+  constexpr int NPL = X6 ? 3 : 2;
+  __shared__ __attribute__((aligned(16))) char lds[NPL * R * RB];   // hi plane, lo plane (X6: hi, mid, lo)
   const int tid = threadIdx.x;
   const int lane = tid & 63, l = lane & 31, kh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -355,15 +357,23 @@ __global__ __launch_bounds__(256, 1) void field_wgrad_x3_kernel(const WgArgs a) 
       const f32x4 v = stg[it];
       // packed conversions, and the rounded values back out of the packed words (shift / mask): scalar casts make
       // the compiler convert every value twice
-      const bf16x4 hi = __builtin_convertvector(v, bf16x4);
       typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-      const u32x2 w = __builtin_bit_cast(u32x2, hi);
-      const f32x4 back = {__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
-                          __builtin_bit_cast(float, w.y << 16), __builtin_bit_cast(float, w.y & 0xffff0000u)};
-      const bf16x4 lo = __builtin_convertvector(v - back, bf16x4);
+      auto back = [](const bf16x4& q) {
+        const u32x2 w = __builtin_bit_cast(u32x2, q);
+        return f32x4{__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
+                     __builtin_bit_cast(float, w.y << 16), __builtin_bit_cast(float, w.y & 0xffff0000u)};
+      };
+      const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+      const f32x4 r1 = v - back(hi);
       char* d = lds + (it * 32 + prow) * RB + ppc * 8;
       *reinterpret_cast<bf16x4*>(d) = hi;
-      *reinterpret_cast<bf16x4*>(d + R * RB) = lo;
+      if constexpr (X6) {
+        const bf16x4 mid = __builtin_convertvector(r1, bf16x4);
+        *reinterpret_cast<bf16x4*>(d + R * RB) = mid;
+        *reinterpret_cast<bf16x4*>(d + 2 * R * RB) = __builtin_convertvector(r1 - back(mid), bf16x4);
+      } else {
+        *reinterpret_cast<bf16x4*>(d + R * RB) = __builtin_convertvector(r1, bf16x4);
+      }
       if (it < OT) bsum[it < OT ? it : 0] += (v.x + v.y) + (v.z + v.w);
     }
   };
@@ -383,25 +393,31 @@ __global__ __launch_bounds__(256, 1) void field_wgrad_x3_kernel(const WgArgs a) 
     const char* pb = lds + (OT * 32 + wc * KTW * 32 + l) * RB + kh * 16;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 ah[OTW], al[OTW], bh[KTW], bl[KTW];
+      // planes: [0] hi, [1] lo (x3) / mid (x6), [2] lo (x6)
+      bf16x8 fa[NPL][OTW], fb[NPL][KTW];
 #pragma unroll
-      for (int i = 0; i < OTW; ++i) {
-        ah[i] = *reinterpret_cast<const bf16x8*>(pa + i * 32 * RB + ks * 32);
-        al[i] = *reinterpret_cast<const bf16x8*>(pa + i * 32 * RB + ks * 32 + R * RB);
-      }
+      for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
-      for (int j = 0; j < KTW; ++j) {
-        bh[j] = *reinterpret_cast<const bf16x8*>(pb + j * 32 * RB + ks * 32);
-        bl[j] = *reinterpret_cast<const bf16x8*>(pb + j * 32 * RB + ks * 32 + R * RB);
+        for (int i = 0; i < OTW; ++i) fa[pl][i] = *reinterpret_cast<const bf16x8*>(pa + i * 32 * RB + ks * 32 + pl * R * RB);
+#pragma unroll
+        for (int j = 0; j < KTW; ++j) fb[pl][j] = *reinterpret_cast<const bf16x8*>(pb + j * 32 * RB + ks * 32 + pl * R * RB);
       }
 #pragma unroll
       for (int i = 0; i < OTW; ++i)
 #pragma unroll
         for (int j = 0; j < KTW; ++j) {
           f32x16 c = acc[i * KTW + j];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], c, 0, 0, 0);
+          if constexpr (X6) {              // small terms first (field_x6.h)
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2][i], fb[0][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[2][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[1][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[0][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[1][j], c, 0, 0, 0);
+          } else {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[1][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[0][j], c, 0, 0, 0);
+          }
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][j], c, 0, 0, 0);
           acc[i * KTW + j] = c;
         }
     }
@@ -442,6 +458,9 @@ __global__ __launch_bounds__(256, 1) void field_wgrad_x3_kernel(const WgArgs a) 
 // Bank conflicts: rows of 64 bytes would put rows l, l+4, l+8, l+12 of a 16-byte read on the same banks; the ring holds
 // piece c of row r at position c ^ ((r >> 2) & 3) instead (the DMA lane fetches the piece that belongs in ITS slot).
 // Past the end of the slice the ring keeps fetching the last tile, so that the wait count is the same in every iteration.
+// X6: every product from exact three-way bf16 splits of both operands (six MFMA products: the forward's bf16x6
+// arithmetic, field_x6.h) instead of the two-way splits' three -- fp32-grade weight gradients.
+template <bool X6>
 __global__ __launch_bounds__(256, 1) void field_wgrad_ring_kernel(const WgArgs a) {
   constexpr int ROWS = 512;                 // 256 G rows, then 256 X rows
   constexpr int HB = ROWS * 64;             // bytes of a half: 16 points x 4 B per row
@@ -488,24 +507,41 @@ __global__ __launch_bounds__(256, 1) void field_wgrad_ring_kernel(const WgArgs a
   auto fetch_row = [&](const char* row) -> Raw {
     return Raw{*reinterpret_cast<const f32x4*>(row + off0), *reinterpret_cast<const f32x4*>(row + off1)};
   };
-  auto split = [&](const Raw& r, bf16x8& hi, bf16x8& lo) {
+  struct F { bf16x8 h, m, l; };            // operand fragment as bf16 planes (m: X6 only)
+  auto split = [&](const Raw& r, F& f) {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    auto back = [](const bf16x4& q) {
+      const u32x2 w = __builtin_bit_cast(u32x2, q);
+      return f32x4{__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
+                   __builtin_bit_cast(float, w.y << 16), __builtin_bit_cast(float, w.y & 0xffff0000u)};
+    };
     const bf16x4 h0 = __builtin_convertvector(r.v0, bf16x4), h1 = __builtin_convertvector(r.v1, bf16x4);
-    const u32x2 w0 = __builtin_bit_cast(u32x2, h0), w1 = __builtin_bit_cast(u32x2, h1);
-    const f32x4 b0 = {__builtin_bit_cast(float, w0.x << 16), __builtin_bit_cast(float, w0.x & 0xffff0000u),
-                      __builtin_bit_cast(float, w0.y << 16), __builtin_bit_cast(float, w0.y & 0xffff0000u)};
-    const f32x4 b1 = {__builtin_bit_cast(float, w1.x << 16), __builtin_bit_cast(float, w1.x & 0xffff0000u),
-                      __builtin_bit_cast(float, w1.y << 16), __builtin_bit_cast(float, w1.y & 0xffff0000u)};
-    const bf16x4 l0 = __builtin_convertvector(r.v0 - b0, bf16x4), l1 = __builtin_convertvector(r.v1 - b1, bf16x4);
-    hi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-    lo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+    const f32x4 r0 = r.v0 - back(h0), r1 = r.v1 - back(h1);
+    f.h = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+    if constexpr (X6) {
+      const bf16x4 m0 = __builtin_convertvector(r0, bf16x4), m1 = __builtin_convertvector(r1, bf16x4);
+      const bf16x4 l0 = __builtin_convertvector(r0 - back(m0), bf16x4), l1 = __builtin_convertvector(r1 - back(m1), bf16x4);
+      f.m = __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7);
+      f.l = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+    } else {
+      const bf16x4 l0 = __builtin_convertvector(r0, bf16x4), l1 = __builtin_convertvector(r1, bf16x4);
+      f.l = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
   };
   auto row_sum = [](const Raw& r) { return ((r.v0.x + r.v0.y) + (r.v0.z + r.v0.w)) + ((r.v1.x + r.v1.y) + (r.v1.z + r.v1.w)); };
-  auto triple = [&](int i, int j, const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl) {
+  auto triple = [&](int i, int j, const F& A, const F& B) {
     f32x16 c = acc[i * KTW + j];
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+    if constexpr (X6) {                    // small terms first (field_x6.h)
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l, B.h, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B.l, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.m, B.m, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.m, B.h, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B.m, c, 0, 0, 0);
+    } else {
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B.l, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l, B.h, c, 0, 0, 0);
+    }
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h, B.h, c, 0, 0, 0);
     acc[i * KTW + j] = c;
   };
 #define DMN_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -518,11 +554,11 @@ __global__ __launch_bounds__(256, 1) void field_wgrad_ring_kernel(const WgArgs a
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // half 0
     __syncthreads();
     // A0 / B0 of the half about to be multiplied are converted at the end of the half before (here: up front)
-    bf16x8 ah[OTW], al[OTW], bh[2], bl[2], nah, nal, nbh, nbl;
+    F fa[OTW], fb[2], nfa, nfb;
     {
       const Raw ra = fetch_row(lds + (wr * OTW * 32 + l) * 64), rb = fetch_row(lds + (256 + wc * KTW * 32 + l) * 64);
-      split(ra, nah, nal);
-      split(rb, nbh, nbl);
+      split(ra, nfa);
+      split(rb, nfb);
       bsum[0] += row_sum(ra);
     }
     for (long h = 0; h < H; ++h) {
@@ -530,61 +566,61 @@ __global__ __launch_bounds__(256, 1) void field_wgrad_ring_kernel(const WgArgs a
       const char* pb = lds + (int)(h & (RING - 1)) * HB + (256 + wc * KTW * 32 + l) * 64;
       const char* na = lds + (int)((h + 1) & (RING - 1)) * HB + (wr * OTW * 32 + l) * 64;
       const char* nb = lds + (int)((h + 1) & (RING - 1)) * HB + (256 + wc * KTW * 32 + l) * 64;
-      ah[0] = nah; al[0] = nal; bh[0] = nbh; bl[0] = nbl;
+      fa[0] = nfa; fb[0] = nfb;
       // the schedule: every MFMA triple carries the conversion of a fragment needed later, raw rows are read one step
       // before they are converted; the ring hand-over (wait, barrier, re-issue) sits in the middle of the half
       Raw r = fetch_row(pa + 1 * 32 * 64);
       DMN_FENCE();
-      triple(0, 0, ah[0], al[0], bh[0], bl[0]);
-      split(r, ah[1], al[1]); bsum[1] += row_sum(r);
+      triple(0, 0, fa[0], fb[0]);
+      split(r, fa[1]); bsum[1] += row_sum(r);
       r = fetch_row(pa + 2 * 32 * 64);
       DMN_FENCE();
-      triple(1, 0, ah[1], al[1], bh[0], bl[0]);
-      split(r, ah[2], al[2]); bsum[2] += row_sum(r);
+      triple(1, 0, fa[1], fb[0]);
+      split(r, fa[2]); bsum[2] += row_sum(r);
       r = fetch_row(pa + 3 * 32 * 64);
       DMN_FENCE();
-      triple(2, 0, ah[2], al[2], bh[0], bl[0]);
-      split(r, ah[3], al[3]); bsum[3] += row_sum(r);
+      triple(2, 0, fa[2], fb[0]);
+      split(r, fa[3]); bsum[3] += row_sum(r);
       r = fetch_row(pb + 1 * 32 * 64);
       DMN_FENCE();
-      triple(3, 0, ah[3], al[3], bh[0], bl[0]);
-      split(r, bh[1], bl[1]);
+      triple(3, 0, fa[3], fb[0]);
+      split(r, fb[1]);
       r = fetch_row(pb + 2 * 32 * 64);
       DMN_FENCE();
-      triple(0, 1, ah[0], al[0], bh[1], bl[1]);
-      split(r, bh[0], bl[0]);                               // B2 (B0 is done)
+      triple(0, 1, fa[0], fb[1]);
+      split(r, fb[0]);                               // B2 (B0 is done)
       r = fetch_row(pb + 3 * 32 * 64);
       DMN_FENCE();
-      triple(1, 1, ah[1], al[1], bh[1], bl[1]);
+      triple(1, 1, fa[1], fb[1]);
       DMN_FENCE();
-      triple(2, 1, ah[2], al[2], bh[1], bl[1]);
+      triple(2, 1, fa[2], fb[1]);
       DMN_FENCE();
-      triple(3, 1, ah[3], al[3], bh[1], bl[1]);
+      triple(3, 1, fa[3], fb[1]);
       DMN_FENCE();
       asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // this wave's pieces of half h+1 (half h+2 stays in flight)
       __syncthreads();                                     // ... everybody's; and everybody is past half h-1
       issue(h + 3);                                        // into the slot of half h-1
       DMN_FENCE();
-      triple(0, 2, ah[0], al[0], bh[0], bl[0]);
-      split(r, bh[1], bl[1]);                               // B3 (B1 is done)
+      triple(0, 2, fa[0], fb[0]);
+      split(r, fb[1]);                               // B3 (B1 is done)
       Raw rn = fetch_row(na);
       DMN_FENCE();
-      triple(1, 2, ah[1], al[1], bh[0], bl[0]);
-      split(rn, nah, nal); bsum[0] += h + 1 < H ? row_sum(rn) : 0.f;
+      triple(1, 2, fa[1], fb[0]);
+      split(rn, nfa); bsum[0] += h + 1 < H ? row_sum(rn) : 0.f;
       rn = fetch_row(nb);
       DMN_FENCE();
-      triple(2, 2, ah[2], al[2], bh[0], bl[0]);
-      split(rn, nbh, nbl);
+      triple(2, 2, fa[2], fb[0]);
+      split(rn, nfb);
       DMN_FENCE();
-      triple(3, 2, ah[3], al[3], bh[0], bl[0]);
+      triple(3, 2, fa[3], fb[0]);
       DMN_FENCE();
-      triple(0, 3, ah[0], al[0], bh[1], bl[1]);
+      triple(0, 3, fa[0], fb[1]);
       DMN_FENCE();
-      triple(1, 3, ah[1], al[1], bh[1], bl[1]);
+      triple(1, 3, fa[1], fb[1]);
       DMN_FENCE();
-      triple(2, 3, ah[2], al[2], bh[1], bl[1]);
+      triple(2, 3, fa[2], fb[1]);
       DMN_FENCE();
-      triple(3, 3, ah[3], al[3], bh[1], bl[1]);
+      triple(3, 3, fa[3], fb[1]);
       DMN_FENCE();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the ring's last (unused) fetches must land before the LDS goes
@@ -634,8 +670,9 @@ __global__ void field_wgrad_reduce_kernel(const float* partial, const int32_t* i
   grads[dst] = accumulate ? grads[dst] + sum : sum;
 }
 
+// mode: 0 exact fp32 MFMA, 1 bf16x3 (three products per product), 2 bf16x6 (six, exact three-way splits)
 template <int OT, int KT, int WR, int WC>
-void launch_class(WgArgs a, const int* ids, int n, bool x3, hipStream_t st) {
+void launch_class(WgArgs a, const int* ids, int n, int mode, hipStream_t st) {
   for (int i = 0; i < n; ++i) a.list[i] = ids[i];
   if (!(OT == 8 && KT == 8)) {             // small GEMMs: more, shorter point slices in their own workspace region
     a.partial += (long)a.splits * kWgradBigLen;
@@ -643,10 +680,14 @@ void launch_class(WgArgs a, const int* ids, int n, bool x3, hipStream_t st) {
     a.elem_base = kWgradBigLen;
     a.splits *= kWgradSmallSplitFactor;
   }
-  if (x3 && OT == 8 && KT == 8)
-    hipLaunchKernelGGL(field_wgrad_ring_kernel, dim3(a.splits, n), dim3(256), 0, st, a);
-  else if (x3)
-    hipLaunchKernelGGL((field_wgrad_x3_kernel<OT, KT, WR, WC>), dim3(a.splits, n), dim3(256), 0, st, a);
+  if (mode == 2 && OT == 8 && KT == 8)
+    hipLaunchKernelGGL(field_wgrad_ring_kernel<true>, dim3(a.splits, n), dim3(256), 0, st, a);
+  else if (mode == 1 && OT == 8 && KT == 8)
+    hipLaunchKernelGGL(field_wgrad_ring_kernel<false>, dim3(a.splits, n), dim3(256), 0, st, a);
+  else if (mode == 2)
+    hipLaunchKernelGGL((field_wgrad_x3_kernel<OT, KT, WR, WC, true>), dim3(a.splits, n), dim3(256), 0, st, a);
+  else if (mode == 1)
+    hipLaunchKernelGGL((field_wgrad_x3_kernel<OT, KT, WR, WC, false>), dim3(a.splits, n), dim3(256), 0, st, a);
   else
     hipLaunchKernelGGL((field_wgrad_kernel<OT, KT, WR, WC>), dim3(a.splits, n), dim3(256), 0, st, a);
 }
@@ -721,8 +762,9 @@ extern "C" int dmn_field_bwd_weights(const float* save, const float* grad_record
                                      const int32_t* wgrad_index, int splits, int precision, float* workspace,
                                      float* grads_flat, int accumulate, void* stream) {
   if (n_points < 0 || ins_num < 0 || splits <= 0 || splits > 65535) return DMN_ERR_BAD_ARG;
-  if (precision != DMN_PREC_FP32 && precision != DMN_PREC_BF16X3) return DMN_ERR_BAD_ARG;   // fp16 underflows on gradients
-  const bool x3 = precision == DMN_PREC_BF16X3;
+  if (precision != DMN_PREC_FP32 && precision != DMN_PREC_BF16X3 && precision != DMN_PREC_BF16X6)
+    return DMN_ERR_BAD_ARG;                                                                     // fp16 underflows on gradients
+  const int x3 = precision == DMN_PREC_BF16X3 ? 1 : (precision == DMN_PREC_BF16X6 ? 2 : 0);     // launch_class mode
   if (n_points == 0) return DMN_OK;
   if (!save || !grad_record || !wgrad_index || !workspace || !grads_flat) return DMN_ERR_BAD_ARG;
   const int T = ins_tiles(ins_num);

@@ -146,6 +146,13 @@ extern "C" int dmn_field_pack_x6(const float* params, const int32_t* index, int 
   return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
 }
 
+// the same gather for any x6-format index table (the backward-data blob: dmn_field_bwd_pack_index_x6)
+extern "C" int dmn_field_pack_x6_n(const float* params, const int32_t* index, long index_len, void* blob, void* stream) {
+  if (!params || !index || !blob || index_len < kConstFloats) return DMN_ERR_BAD_ARG;
+  hipLaunchKernelGGL(pack_x6_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, params, index, index_len, (char*)blob);
+  return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
+}
+
 extern "C" int dmn_field_fwd_rays_x6(const float* rays_o, const float* rays_d, const float* z, long z_ray_stride,
                                      long n_rays, int n_samples, const void* blob, int ins_num, int sigma_only,
                                      float* raw, void* stream) {

@@ -254,6 +254,17 @@ constexpr int kBwdX3Stages = kBwdX3StageRgbF + 4 + 7 * 4;   // 37
 constexpr long kBwdX3StreamHalfs = (long)kBwdX3Stages * kX3StageChunks * kX3ChunkHalfs;
 constexpr long kBwdX3BlobBytes = (long)kConstFloats * 4 + kBwdX3StreamHalfs * 2;
 constexpr long kBwdX3IndexLen = (long)kConstFloats + kBwdX3StreamHalfs;
+// Backward-data stream in the full-precision bf16 format ("x6": 48-chunk stages, k-steps outer, [hi, mid, lo] chunk
+// triples per (k-step, tile) group; field_bwd_x6.hip):
+DMN_HD constexpr int bwd_x6_inso_stages(int T) { return (2 * T + x6_ksteps_per_stage(4) - 1) / x6_ksteps_per_stage(4); }   // 4 tiles x 2T k-steps
+DMN_HD constexpr int bwd_x6_stage_insh(int T) { return bwd_x6_inso_stages(T); }      // ins_feature_linears.0^T: 8 x 8  -> 4 stages
+DMN_HD constexpr int bwd_x6_stage_rgbh(int T) { return bwd_x6_stage_insh(T) + 4; }   // rgb_feature_linears.0^T:  8 x 8  -> 4
+DMN_HD constexpr int bwd_x6_stage_rgbf(int T) { return bwd_x6_stage_rgbh(T) + 4; }   // rgb_feature_linear^T:     8 x 16 -> 8
+DMN_HD constexpr int bwd_x6_stage_mlp(int T, int l) { return bwd_x6_stage_rgbf(T) + 8 + 8 * (7 - l); }   // l = 7..1
+DMN_HD constexpr int bwd_x6_total_stages(int T) { return bwd_x6_stage_rgbf(T) + 8 + 7 * 8; }             // 73 (T <= 2) / 74
+DMN_HD constexpr long bwd_x6_stream_halfs(int T) { return (long)bwd_x6_total_stages(T) * kX6StageChunks * kX3ChunkHalfs; }
+DMN_HD constexpr long bwd_x6_blob_bytes(int ins_num) { return (long)kConstFloats * 4 + bwd_x6_stream_halfs(ins_tiles(ins_num)) * 2; }
+DMN_HD constexpr long bwd_x6_index_len(int ins_num) { return (long)kConstFloats + bwd_x6_stream_halfs(ins_tiles(ins_num)); }
 constexpr int kConstZeros = 3592;      // const floats 3592..3839 are zero padding: initial accumulators of the backward
 
 // Weight-gradient GEMMs: dW[o][k] = sum over points of G[o][point] * X[k][point], G rows from the gradient

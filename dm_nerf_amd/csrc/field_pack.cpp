@@ -118,8 +118,10 @@ void layer_x3(int32_t* stream, int stage0, int n_tiles, int n_ksteps, int w_off,
 // ---- full-precision bf16 stream ("x6": three bf16 planes per weight, k-steps in the outer loop) ----------------
 // One layer: for k-step ks, for tile t: [hi, mid, lo] chunks; kps k-steps per 48-chunk stage (field_layout.h).
 // All three chunks of a (k-step, tile) carry the same gather entries: the plane is the chunk's position modulo 3.
+// transposed: the layer multiplies by W^T (backward data): row indexes W's columns, the k feature its rows.
 template <class Col>
-void layer_x6(int32_t* stream, int stage0, int n_tiles, int n_ksteps, int kps, int w_off, int fan_in, int n_rows, Col col) {
+void layer_x6(int32_t* stream, int stage0, int n_tiles, int n_ksteps, int kps, int w_off, int fan_in, int n_rows, Col col,
+              bool transposed = false) {
   for (int ks = 0; ks < n_ksteps; ++ks)
     for (int t = 0; t < n_tiles; ++t)
       for (int plane = 0; plane < 3; ++plane) {
@@ -129,7 +131,7 @@ void layer_x6(int32_t* stream, int stage0, int n_tiles, int n_ksteps, int kps, i
           for (int j = 0; j < 8; ++j) {
             int row = 32 * t + (lane & 31);
             int k = col(8 * ks + j, lane >> 5);
-            c[lane * 8 + j] = (k < 0 || row >= n_rows) ? -1 : w_off + row * fan_in + k;
+            c[lane * 8 + j] = (k < 0 || row >= n_rows) ? -1 : (transposed ? w_off + k * fan_in + row : w_off + row * fan_in + k);
           }
       }
 }
@@ -330,6 +332,34 @@ extern "C" int dmn_field_bwd_pack_index_x3(int ins_num, int32_t* index_out) {
   layer_x3(s, kBwdX3StageRgbH, 8, 8, P.rgbh_w, kWidth + kDirCh, kWidth, act, true);
   layer_x3(s, kBwdX3StageRgbF, 8, 16, P.rgbf_w, kWidth, kWidth, act, true);
   for (int l = 7; l >= 1; --l) layer_x3(s, bwd_x3_stage_mlp(l), 8, 16, P.mlp_w[l], mlp_fan_in(l), kWidth, act, true);
+  return DMN_OK;
+}
+
+extern "C" long dmn_field_bwd_blob_x6_bytes(int ins_num) {
+  if (!supported(ins_num)) return DMN_ERR_BAD_ARG;
+  return bwd_x6_blob_bytes(ins_num);
+}
+
+extern "C" long dmn_field_bwd_pack_index_x6_len(int ins_num) {
+  if (!supported(ins_num)) return DMN_ERR_BAD_ARG;
+  return bwd_x6_index_len(ins_num);
+}
+
+extern "C" int dmn_field_bwd_pack_index_x6(int ins_num, int32_t* index_out) {
+  if (!index_out || !supported(ins_num)) return DMN_ERR_BAD_ARG;
+  const int T = ins_tiles(ins_num);
+  const ParamOffsets P = param_offsets(ins_num);
+  std::fill(index_out, index_out + bwd_x6_index_len(ins_num), -1);
+  fill_const(index_out, P, ins_num);
+  int32_t* s = index_out + kConstFloats;
+  auto act = [](int i, int h) { return feat_of(i, h); };
+  const int k8 = x6_ksteps_per_stage(8), k4 = x6_ksteps_per_stage(4);
+  layer_x6(s, 0, 4, 2 * T, k4, P.inso_w, kHalf, kHalf,
+           [&](int i, int h) { int ch = feat_of(i, h); return ch <= ins_num ? ch : -1; }, true);
+  layer_x6(s, bwd_x6_stage_insh(T), 8, 8, k8, P.insh_w, kWidth, kWidth, act, true);
+  layer_x6(s, bwd_x6_stage_rgbh(T), 8, 8, k8, P.rgbh_w, kWidth + kDirCh, kWidth, act, true);
+  layer_x6(s, bwd_x6_stage_rgbf(T), 8, 16, k8, P.rgbf_w, kWidth, kWidth, act, true);
+  for (int l = 7; l >= 1; --l) layer_x6(s, bwd_x6_stage_mlp(T, l), 8, 16, k8, P.mlp_w[l], mlp_fan_in(l), kWidth, act, true);
   return DMN_OK;
 }
 

@@ -87,12 +87,12 @@ class DM_NeRF(nn.Module):
         return [p for _, p in self.named_parameters()]      # registration order = state_dict order
 
     def blob(self, precision: str = "fp32") -> torch.Tensor:
-        """Device blob consumed by the field kernel of the given precision ("bwd" / "bwd_x3": the transposed-weight
-        blobs of the exact and the bf16x3 backward-data kernel); re-gathered only when a parameter changed
+        """Device blob consumed by the field kernel of the given precision ("bwd" / "bwd_x6" / "bwd_x3": the
+        transposed-weight blobs of the exact, the bf16x6 and the bf16x3 backward-data kernel); re-gathered only when a parameter changed
         (optimizer steps, ``load_state_dict`` and every other in-place op bump the tensors' version counters).
         Writes THROUGH ``p.data`` (``p.data.mul_(..)``, legacy init / EMA / clipping code) bypass the version counter by
         design of autograd: call ``invalidate_blobs()`` after such a write."""
-        if precision not in ("bwd", "bwd_x3"):
+        if precision not in ("bwd", "bwd_x3", "bwd_x6"):
             ops.precision_code(precision)
         params = self._ordered_params()
         dev = params[0].device
@@ -100,11 +100,11 @@ class DM_NeRF(nn.Module):
         cached = self._blobs.get(precision)
         if cached is not None and cached[0] == key:
             return cached[1]
-        flavour = precision if precision in ("fp32", "bwd", "bwd_x3") else ("x6" if precision == "bf16x6" else "x3")
+        flavour = precision if precision in ("fp32", "bwd", "bwd_x3", "bwd_x6") else ("x6" if precision == "bf16x6" else "x3")
         index = self._indices.get((flavour, dev))
         if index is None:
             make = {"fp32": ops.pack_index, "bwd": ops.bwd_pack_index, "bwd_x3": ops.bwd_pack_index_x3,
-                    "x3": ops.pack_index_x3, "x6": ops.pack_index_x6}[flavour]
+                    "bwd_x6": ops.bwd_pack_index_x6, "x3": ops.pack_index_x3, "x6": ops.pack_index_x6}[flavour]
             index = self._indices[(flavour, dev)] = make(self.ins_num, dev)
         if self._flat is not None and self._flat[0] == key:      # the backward's blob follows the forward's: one gather
             flat = self._flat[1]
@@ -118,6 +118,8 @@ class DM_NeRF(nn.Module):
             blob = ops.pack_blob_x6(flat, index, self.ins_num)
         elif flavour == "bwd_x3":
             blob = ops.pack_bwd_blob_x3(flat, index, self.ins_num)
+        elif flavour == "bwd_x6":
+            blob = ops.pack_bwd_blob_x6(flat, index, self.ins_num)
         else:
             blob = ops.pack_blob(flat, index)
         self._blobs[precision] = (key, blob)

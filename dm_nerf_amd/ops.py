@@ -276,6 +276,25 @@ def pack_bwd_blob_x3(flat_params: torch.Tensor, index: torch.Tensor, ins_num: in
     return blob
 
 
+def bwd_pack_index_x6(ins_num: int, device) -> torch.Tensor:
+    lib = load()
+    n = lib.dmn_field_bwd_pack_index_x6_len(ins_num)
+    if n < 0:
+        raise ValueError(f"ins_num={ins_num} unsupported (ins_num + 1 must be <= {MAX_INS_CHANNELS})")
+    idx = np.empty(n, dtype=np.int32)
+    check(lib.dmn_field_bwd_pack_index_x6(ins_num, idx.ctypes.data), "dmn_field_bwd_pack_index_x6")
+    return torch.from_numpy(idx).to(device)
+
+
+def pack_bwd_blob_x6(flat_params: torch.Tensor, index: torch.Tensor, ins_num: int) -> torch.Tensor:
+    _dev(flat_params, "flat_params")
+    lib = load()
+    blob = torch.empty(lib.dmn_field_bwd_blob_x6_bytes(ins_num), dtype=torch.uint8, device=flat_params.device)
+    check(lib.dmn_field_pack_x6_n(ptr(flat_params), ptr(index), index.numel(), ptr(blob), current_stream()),
+          "dmn_field_pack_x6_n")
+    return blob
+
+
 def wgrad_index(ins_num: int, device) -> torch.Tensor:
     lib = load()
     n = lib.dmn_field_wgrad_index_len(ins_num)
@@ -313,17 +332,35 @@ def field_rays_save(rays_o: torch.Tensor, rays_d: torch.Tensor, z: torch.Tensor,
     return raw, save
 
 
+BACKWARD_PRECISIONS = ("fp32", "bf16x6", "bf16x3")
+BWD_BLOB = {"fp32": "bwd", "bf16x6": "bwd_x6", "bf16x3": "bwd_x3"}        # DM_NeRF.blob() name of the transposed-weight blob
+
+
+def backward_precision(forward_precision: str) -> str:
+    """Arithmetic of the backward kernels (backward-data chain and weight-gradient GEMMs) that goes with a forward: the
+    reference back-propagates in fp32 (train_dmsr.py:62-64), so the fp32-grade forwards get fp32-grade gradients --
+    "fp32" -> the exact-fp32 MFMA kernels, "bf16x6" -> six bf16 products on exact three-way splits -- and only the
+    two-way split forwards ("bf16x3" / "fp16x3", an explicit opt-in) train with 16-operand-bit gradients."""
+    if forward_precision in ("fp32", "bf16x6"):
+        return forward_precision
+    if forward_precision in ("bf16x3", "fp16x3"):
+        return "bf16x3"
+    raise ValueError(f"precision must be one of {sorted(PRECISIONS)}, got {forward_precision!r}")
+
+
 def field_backward(g_raw: torch.Tensor, save: torch.Tensor, bwd_blob: torch.Tensor, ins_num: int,
                    wgrad_idx: torch.Tensor, n_params: int, splits: Optional[int] = None,
                    wgrad_precision: str = "bf16x3", data_precision: str = "fp32",
                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dL/d raw [N,S,C] + save record -> flat parameter gradient (state_dict order).  ``data_precision`` /
-    ``wgrad_precision``: arithmetic of the backward-data chain and of the weight-gradient GEMMs, "fp32" (exact
-    MFMA) or "bf16x3" (three bf16 MFMAs per product); ``bwd_blob`` must be the blob of ``data_precision``.
+    ``wgrad_precision``: arithmetic of the backward-data chain and of the weight-gradient GEMMs: "fp32" (exact
+    MFMA), "bf16x6" (six bf16 MFMAs per product on exact three-way splits of both operands: fp32-grade) or "bf16x3"
+    (three bf16 MFMAs per product, 16 operand bits); ``bwd_blob`` must be the blob of ``data_precision``
+    (``DM_NeRF.blob(BWD_BLOB[data_precision])``).
     ``out``: flat fp32 destination (the scatter table covers every parameter exactly once, so it is overwritten)."""
     for prec in (wgrad_precision, data_precision):
-        if prec not in ("fp32", "bf16x3"):
-            raise ValueError("backward precisions are 'fp32' or 'bf16x3' (gradients underflow fp16)")
+        if prec not in BACKWARD_PRECISIONS:
+            raise ValueError(f"backward precisions are {BACKWARD_PRECISIONS} (gradients underflow fp16)")
     _dev(g_raw, "g_raw")
     g_raw = g_raw.contiguous()
     m = g_raw.shape[0] * g_raw.shape[1]
@@ -341,6 +378,9 @@ def field_backward(g_raw: torch.Tensor, save: torch.Tensor, bwd_blob: torch.Tens
         if data_precision == "fp32":
             check(lib.dmn_field_bwd_data(ptr(g_raw), ptr(save), ptr(bwd_blob), m, ins_num, ptr(grec),
                                          current_stream()), "dmn_field_bwd_data")
+        elif data_precision == "bf16x6":
+            check(lib.dmn_field_bwd_data_x6(ptr(g_raw), ptr(save), ptr(bwd_blob), m, ins_num, ptr(grec),
+                                            current_stream()), "dmn_field_bwd_data_x6")
         else:
             check(lib.dmn_field_bwd_data_x3(ptr(g_raw), ptr(save), ptr(bwd_blob), m, ins_num, ptr(grec),
                                             current_stream()), "dmn_field_bwd_data_x3")

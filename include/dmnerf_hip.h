@@ -184,8 +184,9 @@ int dmn_exchange(float* ori_raw, const float* tar_raw, int* ori_labels, const in
  * record, same image layout; the instance branch stops at the trunk output, dm_nerf.py:95), and the
  * weight-gradient call reduces gradient x input over the points into the flat parameter-gradient vector
  * (state_dict order, dmn_field_param_floats entries).  Forward and backward-data are exact fp32 MFMA; the
- * weight-gradient GEMMs run in DMN_PREC_FP32 or DMN_PREC_BF16X3 (three bf16 MFMAs per product, fp32 accumulate;
- * DMN_PREC_FP16X3 is refused: gradients underflow fp16).
+ * weight-gradient GEMMs run in DMN_PREC_FP32, DMN_PREC_BF16X6 (six bf16 MFMAs per product on exact three-way splits:
+ * fp32-grade, the default of the fp32-grade forwards) or DMN_PREC_BF16X3 (three bf16 MFMAs per product, 16 operand
+ * bits; opt-in), fp32 accumulate; DMN_PREC_FP16X3 is refused: gradients underflow fp16).
  *   dmn_field_save_floats / dmn_field_grad_floats: buffer sizes for n_points
  *   dmn_field_bwd_blob_floats / dmn_field_bwd_pack_index: transposed-weight blob, packed with dmn_field_pack
  *   dmn_field_wgrad_index_len / dmn_field_wgrad_index: scatter table (upload once per ins_num)
@@ -207,6 +208,16 @@ long dmn_field_bwd_blob_x3_bytes(int ins_num);
 long dmn_field_bwd_pack_index_x3_len(int ins_num);
 int dmn_field_bwd_pack_index_x3(int ins_num, int32_t* index_out);
 int dmn_field_bwd_data_x3(const float* g_raw, const float* save, const void* bwd_blob_x3, long n_points, int ins_num,
+                          float* grad_record, void* stream);
+/* full-precision bf16 flavour of the backward-data step (DMN_PREC_BF16X6: six bf16 MFMA products per fp32 product on
+ * exact three-way splits of both operands, csrc/field_bwd_x6.hip) -- the reference back-propagates in fp32
+ * (train_dmsr.py:62-64 through networks/dm_nerf.py:80-106, h.detach() at :95): x6-format transposed-weight blob
+ * (dmn_field_bwd_pack_index_x6 + dmn_field_pack_x6_n) and the kernel; same save / gradient records as the others */
+long dmn_field_bwd_blob_x6_bytes(int ins_num);
+long dmn_field_bwd_pack_index_x6_len(int ins_num);
+int dmn_field_bwd_pack_index_x6(int ins_num, int32_t* index_out);
+int dmn_field_pack_x6_n(const float* params, const int32_t* index, long index_len, void* blob, void* stream);
+int dmn_field_bwd_data_x6(const float* g_raw, const float* save, const void* bwd_blob_x6, long n_points, int ins_num,
                           float* grad_record, void* stream);
 long dmn_field_wgrad_index_len(int ins_num);
 int dmn_field_wgrad_index(int ins_num, int32_t* index_out);

@@ -910,16 +910,18 @@ def _min_abs_preactivation(net, o, d, z):
 
 @pytest.mark.parametrize("fwd,data,wgrad", [("fp32", "fp32", "fp32"), ("fp32", "fp32", "bf16x3"),
                                             ("fp32", "bf16x3", "bf16x3"), ("bf16x3", "bf16x3", "bf16x3"),
-                                            ("bf16x6", "fp32", "fp32"), ("bf16x6", "bf16x3", "bf16x3")])
+                                            ("bf16x6", "fp32", "fp32"), ("bf16x6", "bf16x3", "bf16x3"),
+                                            ("bf16x6", "bf16x6", "bf16x6"), ("fp32", "bf16x6", "bf16x6"),
+                                            ("bf16x6", "bf16x6", "fp32"), ("bf16x6", "fp32", "bf16x6")])
 @pytest.mark.parametrize("ins_num,n,s", [(13, 37, 64), (93, 11, 100), (40, 5, 192), (13, 700, 64), (127, 3, 64)])
 def test_field_backward_kernels_match_library_gemm_backward(ins_num, n, s, fwd, data, wgrad, monkeypatch):
     """HIP backward (save record -> backward-data kernel -> split-K weight-gradient kernel) against autograd
-    through library GEMMs on the device, every parameter of the network, ragged point counts, 1..3 logit tiles."""
+    through library GEMMs on the device, every parameter of the network, ragged point counts, 1..4 logit tiles,
+    every combination of forward / backward-data / weight-gradient arithmetic that ships."""
     from dm_nerf_amd import autograd
     from dm_nerf_amd.autograd import FieldFn
     from library_backward import FieldFnLibrary
-    monkeypatch.setattr(autograd, "WGRAD_PRECISION", wgrad)
-    monkeypatch.setattr(autograd, "DATA_PRECISION", data)
+    monkeypatch.setattr(autograd, "BACKWARD_OVERRIDE", (data, wgrad))
     _, _, net, _, _ = nets(ins_num, 3, 4)
     rng = np.random.default_rng(900 + ins_num + n)
     o, d, _, _ = cases.path_rays(n, seed=31 + n)
@@ -945,11 +947,17 @@ def test_field_backward_kernels_match_library_gemm_backward(ins_num, n, s, fwd, 
             raw_hip = H(raw)
         else:
             np.testing.assert_array_equal(raw_hip, H(raw))          # the saving forward is the same kernel
+    # fp32-grade backward kernels (exact fp32 MFMA, or six bf16 products on exact three-way splits) are held to the
+    # rounding of an fp32 reduction over the points; the two-way split kernels (16 operand bits) to the north-star's 1e-4
+    # (observed: 1.1e-6 .. 2.1e-6 up to 2 368 points in every fp32-grade combination, 4.0e-6 (all exact) .. 6.1e-6 (all
+    # bf16x6) at 44 800 points, where the order of the fp32 reduction over the points is what differs from the library's;
+    # two-way splits 7e-6 .. 1.4e-5)
+    bound = (5e-6 if n * s < 10000 else 8e-6) if data in ("fp32", "bf16x6") and wgrad in ("fp32", "bf16x6") else 1e-4
     worst = 0.0
     for k in grads["lib"]:
         err = rel_err(grads["hip"][k], grads["lib"][k])
         worst = max(worst, err)
-        assert err < 1e-4, (k, err)
+        assert err < bound, (k, err)
     print(f"ins_num={ins_num} M={n * s} forward={fwd} data={data} wgrad={wgrad}: worst rel err vs library backward {worst:.2e}")
 
 

@@ -70,6 +70,9 @@ SIGNATURES = {
     "dmn_field_bwd_pack_index_x3_len": (c_long, [c_int]),
     "dmn_field_bwd_pack_index_x3": (c_int, [c_int, _P]),
     "dmn_field_bwd_data_x3": (c_int, [_P, _P, _P, c_long, c_int, _P, _P]),
+    "dmn_field_pack_index_x6w": (c_int, [c_int, _P]),
+    "dmn_field_fwd_rays_x6w": (c_int, [_P, _P, _P, c_long, c_long, c_int, _P, c_int, c_int, _P, _P]),
+    "dmn_field_fwd_embedded_x6w": (c_int, [_P, c_long, _P, c_int, _P, _P]),
     "dmn_field_bwd_blob_x6_bytes": (c_long, [c_int]),
     "dmn_field_bwd_pack_index_x6_len": (c_long, [c_int]),
     "dmn_field_bwd_pack_index_x6": (c_int, [c_int, _P]),

@@ -37,8 +37,8 @@ class FieldFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rays_o, rays_d, z, model, precision, *params):
         # "fp16x3" trains in bf16x3: fp16 needs its range flag read back between forward and backward
-        fwd = precision if precision in ("fp32", "bf16x6") else "bf16x3"
-        raw, save = ops.field_rays_save(rays_o, rays_d, z, model.blob(fwd), model.ins_num, fwd)
+        fwd = "bf16x6" if precision in ops.X6_PRECISIONS else ("fp32" if precision == "fp32" else "bf16x3")
+        raw, save = ops.field_rays_save(rays_o, rays_d, z, model.blob(ops.save_blob_name(fwd)), model.ins_num, fwd)
         ctx.save, ctx.model = save, model
         ctx.backward_precisions = BACKWARD_OVERRIDE or (ops.backward_precision(fwd),) * 2
         ctx.meta = [(p.shape, p.numel(), p.requires_grad) for p in params]

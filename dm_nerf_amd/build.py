@@ -17,7 +17,7 @@ from concurrent.futures import ThreadPoolExecutor
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libdmnerf_hip.so")
 OBJ = os.path.join(CSRC, "build")
-SOURCES = ["field_fwd.hip", "field_fwd_x3.hip", "field_fwd_x6.hip", "field_fused_x3.hip", "field_bwd.hip", "field_bwd_x3.hip", "field_bwd_x6.hip", "render_ops.hip",
+SOURCES = ["field_fwd.hip", "field_fwd_x3.hip", "field_fwd_x6.hip", "field_fwd_x6w.hip", "field_fused_x3.hip", "field_bwd.hip", "field_bwd_x3.hip", "field_bwd_x6.hip", "render_ops.hip",
            "composite_bwd.hip", "penalizer.hip", "ins_stats.hip", "exchange.hip", "field_pack.cpp", "render_chain.cpp"]
 HEADERS = ["field_layout.h", "field_common.h", "field_stream.h", "field_x3.h", "field_x3_net.h", "field_x6.h", "composite_common.h", "trig.h",
            os.path.join("..", "..", "include", "dmnerf_hip.h")]

@@ -1,0 +1,406 @@
+// Inference field kernel of the full-precision bf16 arithmetic ("bf16x6", field_x6.h) on v_mfma_f32_16x16x32_bf16:
+// encodings -> the whole network -> raw rows (networks/render.py:37-38,49-61,71-83, networks/dm_nerf.py:80-106), the
+// same six-product arithmetic on exact three-way bf16 splits, the same weight bytes and stage map as
+// field_fwd_x6_kernel -- on 16 x 16 tiles with 32-deep k-steps (field_layout.h "x6w").
+//
+// Why the other shape: the kernel runs at the board's power limit, where throughput is power / energy per point.  The
+// 16x16x32 instruction moves half the accumulator traffic per FLOP of 32x32x16 (a quarter of the C/D elements per
+// instruction at half the FLOP), and on this structure -- same LDS bytes, same vector work per group -- the chip holds
+// a 12 % higher clock for 10 % more cycles (tools/mfma_x6_shapes.hip, profiles/r04c_mfma_x6_shapes.txt: +6.5 %).
+//
+// Mapping: a wave's 32 points are two 16-point tiles p = 0, 1; lane l = (n = l & 15, q = l >> 4) holds, for point 16 p + n,
+// features 16 t + 4 q + r (r = 0..3) of every feature tile t.  A layer is H'^T = W H^T as before: weights are the A operand
+// (one [hi, mid, lo] chunk triple per (k-step, feature tile) group feeds BOTH point tiles: 12 MFMAs per triple), the layer
+// before's accumulators are the B operand: the 8 k-slots of lane group q in k-step ks are the four registers of feature
+// tiles 2 ks and 2 ks + 1 -- a k permutation the weight packing absorbs (field_pack.cpp, layer_x6w).  Two accumulator
+// sets (2 x 128 registers) alternate as input and output, a k-step's operands are read, activated and split one
+// k-step ahead in the MFMA shadow, exactly as in field_x6.h.  The saving (training) forward and the fused kernel stay on
+// the 32x32x16 kernel: their save record and compositing slab are tied to its lane map.
+#include <hip/hip_runtime.h>
+
+#include "../../include/dmnerf_hip.h"
+#include "field_x6.h"
+
+using namespace dmn;
+
+namespace {
+
+
+__device__ __forceinline__ float acc_read1(float v) {      // one register of a FINISHED accumulator tile (field_x3.h acc_read)
+  float x;
+  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(v));
+  return x;
+}
+__device__ __forceinline__ f32x4 mfma_w(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+// ---- a layer's input: value of k-slot j (0..7) of k-step ks for point tile p ------------------------------------------
+template <int NT_IN>
+struct SrcTilesW {                       // the accumulators of the layer before
+  const f32x4 (*a)[NT_IN];
+  __device__ __forceinline__ float operator()(int p, int ks, int j) const { return acc_read1(a[p][2 * ks + (j >> 2)][j & 3]); }
+};
+// The encodings, read where they are consumed out of the exchange area in LDS (see the kernel): channel CH0 + 32 ks + 8 q + j
+// of point 16 p + n; `lane_base` = exchange row 8 q, column n of this wave.  Channels past the end are zero padding.
+constexpr int kXchRow = 33;                            // floats per channel row of the exchange: 32 points + 1 (banks)
+template <int CH0, int CHANNELS>
+struct SrcXch {
+  const float* lane_base;
+  int q;
+  __device__ __forceinline__ float operator()(int p, int ks, int j) const {
+    const float x = lane_base[(CH0 + 32 * ks + j) * kXchRow + 16 * p];
+    return 32 * ks + j + 24 >= CHANNELS ? ((32 * ks + j + 8 * q < CHANNELS) ? x : 0.f) : x;     // only q = 3 can run past the end
+  }
+};
+// h8 = relu(mlps.7) for its second reader (ins_feature_linear): feature tiles 0 .. kKeepTo-1 activated in vector registers
+// (kept by rgb_feature_linear's operand split, see x6w_network), tiles kKeepTo .. 15 still in their accumulators.
+// The FIRST ten tiles: rgb_feature_linear consumes its input tiles in ascending order, so the tiles that must outlive it in
+// accumulator registers are the ones it releases last -- its own output (128 registers) then meets at most 96 of h8, never
+// all 128.  (Keeping the last tiles in vector registers instead leaves the allocator without a spare tuple for the first
+// k-steps: it moves finished tiles of h8 to vector registers and on to scratch, 116 - 164 B per lane, and that traffic
+// evicts the weight stream from the L2: FETCH_SIZE 5.7 GB per launch against 0.85.)
+constexpr int kKeepTo = 10;
+constexpr int kKeepRegs = 4 * kKeepTo;
+struct SrcH8W {
+  const f32x4 (*a)[16];
+  const float (*keep)[kKeepRegs];
+  __device__ __forceinline__ float operator()(int p, int ks, int j) const {
+    const int t = 2 * ks + (j >> 2);
+    return t < kKeepTo ? keep[p][t < kKeepTo ? t * 4 + (j & 3) : 0] : relu_bits(acc_read1(a[p][t < kKeepTo ? 15 : t][j & 3]));
+  }
+};
+
+// One layer, k-steps outer: out[p][t] (t < NT feature tiles of 16, p = 0, 1) = bias + sum over the NKS k-steps of `src`
+// (ReLU first if RELU) and the NKX k-steps of `ext` (encodings) of the six-term product with the stream's chunk triples.
+//   bias   LDS address of this lane group's bias floats of tile 0 (natural feature order: + 16 t per tile)
+//   KEEP   the activated values of source tiles 0 .. kKeepTo-1 stay behind in keep[p][4 t + r]
+//   LAST   the layer ends the weight stream: no LDS-DMA is issued during its last stage
+template <int LID, int NT, int NKS, int NKX, bool RELU, bool KEEP, bool LAST, class Src, class Ext>
+__device__ __forceinline__ void layer_w(Ctx6& c, f32x4 (*out)[NT], const float* bias, const Src& src, const Ext& ext,
+                                        float (*keep)[kKeepRegs] = nullptr) {
+  constexpr int NK = NKS + NKX;
+  constexpr int KPS = x6w_kps(NT);              // k-steps per 16-group stage
+  constexpr bool NTP = ((DMN_X6_NTMASK >> LID) & 1) != 0;
+  static_assert(KPS >= 1 && KPS * NT * 3 <= kX6StageChunks, "a stage holds three chunks per group");
+  // bias = initial accumulator of both point tiles: handed to the first MFMA of a tile's chain in k-step 0, read from LDS one
+  // group ahead.  (All 16 bias tuples loaded up front sit in accumulator registers beside the two full accumulator sets:
+  // the allocator then moves finished tiles to vector registers and, a layer later, to scratch.)
+  f32x4 bias_next = *reinterpret_cast<const f32x4*>(bias);
+  // value pair pr (0..7) of k-step ks: point tile pr >> 2, k-slots 2 (pr & 3), 2 (pr & 3) + 1
+  auto build_pair = [&](int ks, int pr, frag* fh, frag* fm, frag* fl) {
+    const int p = pr >> 2, jp = pr & 3;
+    float x0, x1;
+    if (ks < NKS) {
+      x0 = src(p, ks, 2 * jp);
+      x1 = src(p, ks, 2 * jp + 1);
+      if (RELU) {
+        x0 = relu_bits(x0);
+        x1 = relu_bits(x1);
+      }
+      const int t = 2 * ks + (jp >> 1);         // source feature tile
+      if (KEEP && t < kKeepTo) {
+        keep[p][t * 4 + 2 * (jp & 1)] = x0;
+        keep[p][t * 4 + 2 * (jp & 1) + 1] = x1;
+      }
+    } else {
+      x0 = ext(p, ks - NKS, 2 * jp);
+      x1 = ext(p, ks - NKS, 2 * jp + 1);
+    }
+    split3_pair(x0, x1, fh[p], fm[p], fl[p], 2 * jp);
+  };
+  frag bh[2], bm[2], bl[2], nh[2], nm[2], nl[2];
+#pragma unroll
+  for (int pr = 0; pr < 8; ++pr) build_pair(0, pr, bh, bm, bl);
+  frag ah[2], am[2], al[2];                     // A fragments of the running group and of the next one
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) {
+    constexpr int kLastStage = (NK - 1) / KPS;
+    const int stage = ks / KPS;
+    const int groups = (stage == kLastStage ? NK - stage * KPS : KPS) * NT;
+    const bool dma = !(LAST && stage == kLastStage);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int gi = (ks % KPS) * NT + t;       // group inside its stage
+      const int ar = (ks * NT + t) & 1;
+      if (gi == 0) {
+        x6_stage_begin(c);
+        ah[ar] = *reinterpret_cast<const frag*>(c.buf);
+        am[ar] = *reinterpret_cast<const frag*>(c.buf + 1024);
+        al[ar] = *reinterpret_cast<const frag*>(c.buf + 2048);
+      }
+      if (gi + 1 < groups) {                    // next group's fragments fly under this group's MFMAs
+        ah[ar ^ 1] = *reinterpret_cast<const frag*>(c.buf + (3 * (gi + 1)) * 1024);
+        am[ar ^ 1] = *reinterpret_cast<const frag*>(c.buf + (3 * (gi + 1) + 1) * 1024);
+        al[ar ^ 1] = *reinterpret_cast<const frag*>(c.buf + (3 * (gi + 1) + 2) * 1024);
+      }
+      f32x4 bias_cur = bias_next;
+      if (ks == 0 && t + 1 < NT) bias_next = *reinterpret_cast<const f32x4*>(bias + 16 * (t + 1));
+      __builtin_amdgcn_sched_barrier(0);        // keep the prefetch above this group's MFMAs
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {             // small terms first (field_x6.h)
+        out[p][t] = mfma_w(al[ar], bh[p], ks == 0 ? bias_cur : out[p][t]);
+        out[p][t] = mfma_w(ah[ar], bl[p], out[p][t]);
+        out[p][t] = mfma_w(am[ar], bm[p], out[p][t]);
+        out[p][t] = mfma_w(am[ar], bh[p], out[p][t]);
+        out[p][t] = mfma_w(ah[ar], bm[p], out[p][t]);
+        out[p][t] = mfma_w(ah[ar], bh[p], out[p][t]);
+      }
+      if (dma) {
+        if (gi < kX6PiecesPerWave) x6_piece<NTP>(c, gi);
+        if (gi + 1 == groups) {                 // a short stage still owes the rest of its pieces
+#pragma unroll
+          for (int qq = gi + 1; qq < kX6PiecesPerWave; ++qq) x6_piece<NTP>(c, qq);
+        }
+      }
+      if (ks + 1 < NK) {                        // the next k-step's operand fragments, spread over the tiles
+#pragma unroll
+        for (int pr = 0; pr < 8; ++pr)
+          if ((pr * NT) / 8 == t) build_pair(ks + 1, pr, nh, nm, nl);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      bh[p] = nh[p];
+      bm[p] = nm[p];
+      bl[p] = nl[p];
+    }
+  }
+}
+
+// sum over the four lane groups of a point (q = lane >> 4)
+__device__ __forceinline__ float sum_groups(float x) {
+  x += __shfl_xor(x, 16);
+  x += __shfl_xor(x, 32);
+  return x;
+}
+
+// The whole network on this wave's 32 points (networks/dm_nerf.py:80-106).  xch_lane: this lane's base in the encoding
+// exchange (SrcXch).  Outputs per point tile (valid in all four lane groups): sigma[p], rgb[p][3];
+// acc3[p][t][r] = instance logit of channel 16 t + 4 q + r.  With sigma_only the network stops behind its density head
+// and returns true (see x6_network).
+template <int T16>
+__device__ __forceinline__ bool x6w_network(Ctx6& c, const float* cst, const float* xch_lane, int q,
+                                            bool sigma_only, float (&sigma)[2], float (&rgb)[2][3], f32x4 (&acc3)[2][T16]) {
+  f32x4 accA[2][16], accB[2][16];
+  const SrcXch<0, kPosCh> s_pe{xch_lane, q};
+  const SrcXch<kPosCh, kPosCh + kDirCh> s_qe{xch_lane, q};
+  const SrcTilesW<16> s_a{accA}, s_b{accB};
+  const float* const b8 = cst + kConstBias8 + 4 * q;
+
+  const_section_ready();      // mlps.0 reads its bias before its first stage barrier; the encoding exchange is over
+  // ---- mlps.0: position encoding (2 k-steps) -> A
+  layer_w<0, 16, 2, 0, false, false, false>(c, accA, b8, s_pe, s_pe);
+  // ---- mlps.1 .. mlps.4 in pairs A -> B -> A (rolled)
+#pragma unroll 1
+  for (int l = 1; l < 5; l += 2) {
+    layer_w<1, 16, 8, 0, true, false, false>(c, accB, b8 + l * 256, s_a, s_pe);
+    layer_w<1, 16, 8, 0, true, false, false>(c, accA, b8 + (l + 1) * 256, s_b, s_pe);
+  }
+  // ---- mlps.5 on cat([h, input_pts]) (dm_nerf.py:86-87), mlps.6, mlps.7: A -> B -> A -> B   (c.g: see x6_network)
+  c.g = kX6StageL5;
+  layer_w<2, 16, 8, 2, true, false, false>(c, accB, b8 + 5 * 256, s_a, s_pe);
+  c.g = kX6StageL6;
+  layer_w<3, 16, 8, 0, true, false, false>(c, accA, b8 + 6 * 256, s_b, s_pe);
+  c.g = kX6StageL6 + 8;
+  layer_w<4, 16, 8, 0, true, false, false>(c, accB, b8 + 7 * 256, s_a, s_pe);
+
+  // ---- density_linear on h8 = relu(B) (dm_nerf.py:101): 256 -> 1 on the VALU, 64 terms per lane and point.  h8 is read
+  //      again by the next two layers, so it is read here as they read it (acc_read1: the tiles stay where they are; given
+  //      plain reads the compiler keeps vector-register copies of ten tiles alive across rgb_feature_linear and spills
+  //      them).  Inline asm gets no MFMA -> VALU wait states from the compiler: tiles in ascending order put >= 12 MFMAs
+  //      between a tile's last MFMA and its read, except for the last ones, which the s_nops cover.
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {               // (a tile at a time: left free, all 64 weight reads are hoisted together)
+      const f32x4 w = *reinterpret_cast<const f32x4*>(cst + kConstDensW + 16 * t + 4 * q);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s = fmaf(relu_bits(acc_read1(accB[p][t][r])), w[r], s);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    sigma[p] = sum_groups(s) + cst[kConstDensB];
+  }
+  if (sigma_only) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next stage's LDS-DMA must land before the LDS is let go of
+    return true;
+  }
+
+  // ---- rgb_feature_linear on h8 (no activation behind it, dm_nerf.py:89) -> A; feature tiles 0 .. kKeepTo-1 of h8 stay
+  //      behind activated in vector registers, their accumulators take the 8-tile layers' output
+  float keep[2][kKeepRegs];
+  f32x4 acc2[2][8];
+  c.g = kX6StageRgbF;
+  layer_w<5, 16, 8, 0, true, true, false>(c, accA, b8 + 8 * 256, s_b, s_pe, keep);
+  // ---- rgb_feature_linears.0 on cat([feature, dirs]) -> 128, ReLU (dm_nerf.py:90-93); rgb_linear on the VALU (:102)
+  c.g = kX6StageRgbH;
+  layer_w<6, 8, 8, 1, false, false, false>(c, acc2, cst + kConstBias4 + 4 * q, s_a, s_qe);
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    float s[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(cst + kConstRgbW + k * 128 + 16 * t + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[k] = fmaf(relu_bits(acc2[p][t][r]), w[r], s[k]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rgb[p][k] = sum_groups(s[k]) + cst[kConstRgbB + k];
+  }
+  // ---- ins_feature_linear on the same trunk output (h.detach(), dm_nerf.py:95-96), no activation -> A;
+  //      ins_feature_linears.0 -> 128, ReLU (:97-99); ins_linear -> ins_num + 1 (:103)
+  c.g = kX6StageInsF;
+  layer_w<7, 16, 8, 0, false, false, false>(c, accA, b8 + 9 * 256, SrcH8W{accB, keep}, s_pe);
+  c.g = kX6StageInsH;
+  layer_w<8, 8, 8, 0, false, false, false>(c, acc2, cst + kConstBias4 + 128 + 4 * q, s_a, s_pe);
+  c.g = kX6StageInsO;
+  layer_w<9, T16, 4, 0, true, false, true>(c, acc3, cst + kConstBiasO + 4 * q, SrcTilesW<8>{acc2}, s_pe);
+  return false;
+}
+
+// (store_rows_coalesced: field_fwd_x6.hip; repeated here, both are file-local)
+__device__ __forceinline__ void store_rows_coalesced_w(const float* stage, float* dst, int n_floats, int tid) {
+  const int nvec = n_floats >> 2;
+  for (int i = tid; i < nvec; i += 256)
+    __builtin_nontemporal_store(reinterpret_cast<const f32x4*>(stage)[i], reinterpret_cast<f32x4*>(dst) + i);
+  const int rest = n_floats & 3;
+  if (tid < rest) __builtin_nontemporal_store(stage[4 * nvec + tid], dst + 4 * nvec + tid);
+}
+
+constexpr int kXchWave = (kPosCh + kDirCh) * kXchRow;  // 2,970 floats per wave
+constexpr int kXchBytes = 4 * kXchWave * 4;            // 47,520 B behind the stage slots and the const section
+static_assert(kX6LdsBytes + kXchBytes <= 160 * 1024, "LDS budget of one CU");
+
+template <int T16>
+__global__ __launch_bounds__(256, 1) void field_fwd_x6w_kernel(const FieldArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[kX6LdsBytes + kXchBytes];
+  float* const cst = reinterpret_cast<float*>(lds + kX6Slots * kX6StageBytes);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, n = lane & 15, q = lane >> 4;
+  const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const char* const blob = static_cast<const char*>(a.blob);
+  Ctx6 c{blob + kConstFloats * 4, lds, nullptr, 0, x6_total_stages(ins_tiles(a.ins_ch - 1)), wave_s, lane};
+
+  // const section + stage 0 start streaming while the encodings are computed
+  for (int k = wave_s; k < kConstChunks; k += 4)
+    glds16(blob + k * 1024 + lane * 16, lds + kX6Slots * kX6StageBytes + k * 1024);
+  x6_load_stage(c, 0);
+
+  // ---- encodings: computed as everywhere else (lane = point + 32 * half: half 0 the sin terms, half 1 the cos terms of
+  //      one point), then left in LDS for the lanes that need them as k-slots: lane (n, q) of point tile p takes channels
+  //      32 e + 8 q + j of point 16 p + n, where the layers consume them (SrcXch: 80 reads per pass; held in registers
+  //      they cost 48 for most of the kernel).  Rows of 33 floats keep the 32 points of a channel on 32 banks.
+  float* const xch = reinterpret_cast<float*>(lds + kX6LdsBytes) + wave_s * kXchWave;
+  {
+    const int pt = lane & 31, h = lane >> 5;
+    const long m = ((long)blockIdx.x * 4 + wave_s) * 32 + pt;
+    const long mc = m < a.M ? m : a.M - 1;
+    float pe32[32], qe16[16];
+    point_encodings(a, mc, h, pe32, qe16);
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const int c0 = pos_slot(j, 0), c1 = pos_slot(j, 1);
+      const int ch = h ? c1 : c0;
+      if (ch >= 0) xch[(ch >= 0 ? ch : 0) * kXchRow + pt] = pe32[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int c0 = dir_slot(j, 0), c1 = dir_slot(j, 1);
+      const int ch = h ? c1 : c0;
+      if (ch >= 0) xch[(kPosCh + (ch >= 0 ? ch : 0)) * kXchRow + pt] = qe16[j];
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): written before this wave's first read (same wave: in order anyway)
+  }
+  const float* const xch_lane = xch + 8 * q * kXchRow + n;
+
+  float sigma[2], rgb[2][3];
+  f32x4 acc3[2][T16];
+  const int C = 4 + a.ins_ch;
+  float* const stage = reinterpret_cast<float*>(lds);                 // the stage buffers, once the network is through
+  const long first = (long)blockIdx.x * 128;
+  const int n_out = (int)(a.M - first < 128 ? a.M - first : 128) * C;
+  if (x6w_network<T16>(c, cst, xch_lane, q, a.sigma_only != 0, sigma, rgb, acc3)) {
+    // density only: raw = [0, 0, 0, sigma, 0 ...] (a branch of its own that ends the kernel: field_fwd_x6.hip)
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      float* const row = stage + (wave_s * 32 + 16 * p + n) * C;
+      if (q == 0) {
+        row[0] = 0.f; row[1] = 0.f; row[2] = 0.f;
+        row[3] = sigma[p];
+      }
+#pragma unroll
+      for (int t = 0; t < T16; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ch = 16 * t + 4 * q + r;
+          if (ch < a.ins_ch) row[4 + ch] = 0.f;
+        }
+    }
+    __syncthreads();
+    store_rows_coalesced_w(stage, a.raw + first * C, n_out, tid);
+    return;
+  }
+  // ---- raw = cat([rgb, density, ins]) (dm_nerf.py:105): gathered in LDS, stored as whole lines (field_fwd_x6.hip)
+  __syncthreads();                                   // every wave is done with the last weight stage (no DMA in flight)
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    float* const row = stage + (wave_s * 32 + 16 * p + n) * C;
+    if (q == 0) {
+      row[0] = rgb[p][0]; row[1] = rgb[p][1]; row[2] = rgb[p][2];
+      row[3] = sigma[p];
+    }
+#pragma unroll
+    for (int t = 0; t < T16; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ch = 16 * t + 4 * q + r;
+        if (ch < a.ins_ch) row[4 + ch] = acc3[p][t][r];
+      }
+  }
+  __syncthreads();
+  store_rows_coalesced_w(stage, a.raw + first * C, n_out, tid);
+}
+
+int launch_x6w(const FieldArgs& a, int ins_num, hipStream_t st) {
+  if (ins_num < 0 || ins_tiles(ins_num) > kMaxInsTiles) return DMN_ERR_UNSUPPORTED;
+  if (a.M <= 0) return DMN_OK;
+  const long blocks = (a.M + 127) / 128;
+  if (blocks > 0x7fffffffL) return DMN_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)blocks), block(256);
+  switch (x6w_ins_tiles(ins_num)) {
+    case 1: hipLaunchKernelGGL(field_fwd_x6w_kernel<1>, grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL(field_fwd_x6w_kernel<2>, grid, block, 0, st, a); break;
+    case 4: hipLaunchKernelGGL(field_fwd_x6w_kernel<4>, grid, block, 0, st, a); break;
+    default: return DMN_ERR_UNSUPPORTED;      // more than 64 channels (6 or 8 instance tiles): the acc3 tiles no longer fit
+                                               // beside the two accumulator sets (7 KB of scratch): field_fwd_x6_kernel serves them
+  }
+  return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" int dmn_field_fwd_rays_x6w(const float* rays_o, const float* rays_d, const float* z, long z_ray_stride,
+                                      long n_rays, int n_samples, const void* blob, int ins_num, int sigma_only,
+                                      float* raw, void* stream) {
+  if (n_rays < 0 || n_samples <= 0 || ins_num < 0 || z_ray_stride < 0) return DMN_ERR_BAD_ARG;
+  if (n_rays == 0) return DMN_OK;
+  if (!rays_o || !rays_d || !z || !blob || !raw) return DMN_ERR_BAD_ARG;
+  FieldArgs a{rays_o, rays_d, z, z_ray_stride, nullptr, blob, raw, nullptr, n_rays * (long)n_samples, n_samples,
+              ins_num + 1, nullptr, sigma_only ? 1 : 0};
+  return launch_x6w(a, ins_num, (hipStream_t)stream);
+}
+
+extern "C" int dmn_field_fwd_embedded_x6w(const float* embedded, long n_points, const void* blob, int ins_num,
+                                          float* raw, void* stream) {
+  if (n_points < 0 || ins_num < 0) return DMN_ERR_BAD_ARG;
+  if (n_points == 0) return DMN_OK;
+  if (!embedded || !blob || !raw) return DMN_ERR_BAD_ARG;
+  FieldArgs a{nullptr, nullptr, nullptr, 0, embedded, blob, raw, nullptr, n_points, 1, ins_num + 1, nullptr, 0};
+  return launch_x6w(a, ins_num, (hipStream_t)stream);
+}

@@ -195,6 +195,28 @@ DMN_HD constexpr long x6_blob_bytes(int ins_num) { return (long)kConstFloats * 4
 DMN_HD constexpr long x6_index_len(int ins_num) { return (long)kConstFloats + x6_stream_halfs(ins_tiles(ins_num)); }
 
 // =====================================================================================
+// "x6w": the full-precision bf16 arithmetic of "x6" on v_mfma_f32_16x16x32_bf16 (inference kernel, field_fwd_x6w.hip).
+// Same bytes, same stage map (kX6Stage*, x6_total_stages), same [hi, mid, lo] chunk triples per (k-step, tile) group
+// -- but a tile is 16 features x 16 points and a k-step covers 32 k-values:
+//   lane l: n = l & 15 (point of a 16-point tile; a wave's 32 points are point tiles p = 0, 1), q = l >> 4
+//   accumulator register r (0..3) of feature tile t holds feature 16 t + 4 q + r        (C/D map of the instruction)
+//   A chunk (k-step ks, feature tile t): [lane][j] = W[16 t + (lane & 15)][col(ks, lane >> 4, j)], 64 lanes x 8 halves
+//   B operand: lane group q supplies k-slots 8 q .. 8 q + 7 of the k-step.  Read out of the accumulators of the layer
+//   before, the eight slots are the four registers of feature tiles 2 ks and 2 ks + 1: slot j is feature
+//   x6w_feat(ks, q, j); encodings are laid out directly: slot j of group q in k-step e is channel 32 e + 8 q + j.
+// The const section has the SAME offsets (kConstBias8 ...) but natural feature order: [kConstBias8 + s*256 + f],
+// [kConstBias4 + s*128 + f], [kConstBiasO + f], [kConstDensW + f], [kConstRgbW + c*128 + f].
+// 16 groups per 48-chunk stage: a layer of n feature tiles fits 16 / n k-steps into a stage.
+// =====================================================================================
+DMN_HD constexpr int x6w_feat(int ks, int q, int j) { return 32 * ks + (j < 4 ? 4 * q + j : 16 + 4 * q + (j - 4)); }
+DMN_HD constexpr int x6w_kps(int n_tiles) { return 16 / n_tiles; }                 // k-steps per stage (n_tiles <= 16)
+// feature tiles of the ins_linear layer: the kernel is instantiated for 1, 2, 4, 6, 8 tiles of 16 channels
+DMN_HD constexpr int x6w_ins_tiles(int ins_num) {
+  const int need = (ins_num + 1 + 15) / 16;
+  return need <= 2 ? need : (need <= 4 ? 4 : (need <= 6 ? 6 : 8));
+}
+
+// =====================================================================================
 // Training (backward of the field; train_dmsr.py:32-64 drives it through autograd).
 //
 // Per-point state crosses HBM as "register images": what a wave of the field kernels holds for its 32

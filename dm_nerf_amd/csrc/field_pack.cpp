@@ -136,7 +136,78 @@ void layer_x6(int32_t* stream, int stage0, int n_tiles, int n_ksteps, int kps, i
       }
 }
 
+// ---- "x6w" stream: the x6 planes for v_mfma_f32_16x16x32_bf16 (field_layout.h "x6w") ---------------------------------
+// col(ks, q, j): input column of k-slot j of lane group q in k-step ks, or -1.
+template <class Col>
+void layer_x6w(int32_t* stream, int stage0, int n_tiles, int n_ksteps, int w_off, int fan_in, int n_rows, Col col) {
+  const int kps = x6w_kps(n_tiles);
+  for (int ks = 0; ks < n_ksteps; ++ks)
+    for (int t = 0; t < n_tiles; ++t)
+      for (int plane = 0; plane < 3; ++plane) {
+        long chunk = (long)(stage0 + ks / kps) * kX6StageChunks + (long)((ks % kps) * n_tiles + t) * 3 + plane;
+        int32_t* c = stream + chunk * kX3ChunkHalfs;
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            int row = 16 * t + (lane & 15);
+            int k = col(ks, lane >> 4, j);
+            c[lane * 8 + j] = (k < 0 || row >= n_rows) ? -1 : w_off + row * fan_in + k;
+          }
+      }
+}
+
+// const section in natural feature order
+void fill_const_x6w(int32_t* cst, const ParamOffsets& P, int ins_num) {
+  for (int slot = 0; slot < 10; ++slot) {
+    int bias = slot < 8 ? P.mlp_b[slot] : (slot == 8 ? P.rgbf_b : P.insf_b);
+    for (int f = 0; f < 256; ++f) cst[kConstBias8 + slot * 256 + f] = bias + f;
+  }
+  for (int f = 0; f < 128; ++f) {
+    cst[kConstBias4 + f] = P.rgbh_b + f;
+    cst[kConstBias4 + 128 + f] = P.insh_b + f;
+    cst[kConstBiasO + f] = f <= ins_num ? P.inso_b + f : -1;
+  }
+  for (int f = 0; f < 256; ++f) cst[kConstDensW + f] = P.dens_w + f;
+  cst[kConstDensB] = P.dens_b;
+  for (int c = 0; c < 3; ++c) {
+    for (int f = 0; f < 128; ++f) cst[kConstRgbW + c * 128 + f] = P.rgbo_w + c * kHalf + f;
+    cst[kConstRgbB + c] = P.rgbo_b + c;
+  }
+}
+
 }  // namespace
+
+extern "C" int dmn_field_pack_index_x6w(int ins_num, int32_t* index_out) {
+  if (!index_out || !supported(ins_num)) return DMN_ERR_BAD_ARG;
+  const int T16 = x6w_ins_tiles(ins_num);
+  const ParamOffsets P = param_offsets(ins_num);
+  std::fill(index_out, index_out + x6_index_len(ins_num), -1);
+  fill_const_x6w(index_out, P, ins_num);
+  int32_t* s = index_out + kConstFloats;
+  auto act = [](int ks, int q, int j) { return x6w_feat(ks, q, j); };
+  auto enc = [](int e, int q, int j, int channels) { int c = 32 * e + 8 * q + j; return c < channels ? c : -1; };
+
+  layer_x6w(s, kX6StageL0, 16, 2, P.mlp_w[0], kPosCh, kWidth, [&](int ks, int q, int j) { return enc(ks, q, j, kPosCh); });
+  for (int l = 1; l < kDepth; ++l) {
+    if (l == kSkipLayer)                                           // cat([h, input_pts]) (dm_nerf.py:87)
+      layer_x6w(s, x6_mlp_stage(l), 16, 10, P.mlp_w[l], mlp_fan_in(l), kWidth, [&](int ks, int q, int j) {
+        if (ks < 8) return x6w_feat(ks, q, j);
+        int c = enc(ks - 8, q, j, kPosCh);
+        return c < 0 ? -1 : kWidth + c;
+      });
+    else
+      layer_x6w(s, x6_mlp_stage(l), 16, 8, P.mlp_w[l], kWidth, kWidth, act);
+  }
+  layer_x6w(s, kX6StageRgbF, 16, 8, P.rgbf_w, kWidth, kWidth, act);
+  layer_x6w(s, kX6StageRgbH, 8, 9, P.rgbh_w, kWidth + kDirCh, kHalf, [&](int ks, int q, int j) {   // cat([feature, dirs])
+    if (ks < 8) return x6w_feat(ks, q, j);
+    int c = enc(0, q, j, kDirCh);
+    return c < 0 ? -1 : kWidth + c;
+  });
+  layer_x6w(s, kX6StageInsF, 16, 8, P.insf_w, kWidth, kWidth, act);
+  layer_x6w(s, kX6StageInsH, 8, 8, P.insh_w, kWidth, kHalf, act);
+  layer_x6w(s, kX6StageInsO, T16, 4, P.inso_w, kHalf, ins_num + 1, act);
+  return DMN_OK;
+}
 
 extern "C" long dmn_field_blob_x6_bytes(int ins_num) {
   if (!supported(ins_num)) return DMN_ERR_BAD_ARG;

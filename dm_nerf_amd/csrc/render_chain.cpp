@@ -41,6 +41,8 @@ extern "C" int dmn_render_rays(const float* rays_o, const float* rays_d, const f
                                 stream);
     if (precision == DMN_PREC_BF16X6)
       return dmn_field_fwd_rays_x6(rays_o, rays_d, z, stride, n_rays, n_s, blob, ins_num, 0, raw, stream);
+    if (precision == DMN_PREC_BF16X6W)
+      return dmn_field_fwd_rays_x6w(rays_o, rays_d, z, stride, n_rays, n_s, blob, ins_num, 0, raw, stream);
     return dmn_field_fwd_rays_x3(rays_o, rays_d, z, stride, n_rays, n_s, blob, ins_num, precision, raw, status, stream);
   };
   if ((rc = field(zc, zs, S, blob_coarse, raw_c)) != DMN_OK) return rc;

@@ -100,11 +100,17 @@ class DM_NeRF(nn.Module):
         cached = self._blobs.get(precision)
         if cached is not None and cached[0] == key:
             return cached[1]
-        flavour = precision if precision in ("fp32", "bwd", "bwd_x3", "bwd_x6") else ("x6" if precision == "bf16x6" else "x3")
+        if precision in ("fp32", "bwd", "bwd_x3", "bwd_x6"):
+            flavour = precision
+        elif precision in ops.X6_PRECISIONS:       # inference on the 16x16x32 kernel where it exists, else the 32x32x16 one
+            flavour = "x6w" if ops.uses_x6w(self.ins_num, precision) else "x6"
+        else:
+            flavour = "x3"
         index = self._indices.get((flavour, dev))
         if index is None:
             make = {"fp32": ops.pack_index, "bwd": ops.bwd_pack_index, "bwd_x3": ops.bwd_pack_index_x3,
-                    "bwd_x6": ops.bwd_pack_index_x6, "x3": ops.pack_index_x3, "x6": ops.pack_index_x6}[flavour]
+                    "bwd_x6": ops.bwd_pack_index_x6, "x3": ops.pack_index_x3, "x6": ops.pack_index_x6,
+                    "x6w": ops.pack_index_x6w}[flavour]
             index = self._indices[(flavour, dev)] = make(self.ins_num, dev)
         if self._flat is not None and self._flat[0] == key:      # the backward's blob follows the forward's: one gather
             flat = self._flat[1]
@@ -114,7 +120,7 @@ class DM_NeRF(nn.Module):
             self._flat = (key, flat)
         if flavour == "x3":
             blob = ops.pack_blob_x3(flat, index, self.ins_num, precision)
-        elif flavour == "x6":
+        elif flavour in ("x6", "x6w"):             # same gather kernel: the plane is the chunk's position modulo 3
             blob = ops.pack_blob_x6(flat, index, self.ins_num)
         elif flavour == "bwd_x3":
             blob = ops.pack_bwd_blob_x3(flat, index, self.ins_num)

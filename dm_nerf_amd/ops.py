@@ -15,7 +15,27 @@ from ._lib import check, current_stream, load, ptr
 MAX_INS_CHANNELS = 128
 
 # arithmetic of the field kernel (include/dmnerf_hip.h DMN_PREC_*)
-PRECISIONS = {"fp32": 0, "fp16x3": 1, "bf16x3": 2, "bf16x6": 3}
+# "bf16x6_32": the bf16x6 arithmetic on the 32x32x16 kernel that also has a saving (training) and a fused variant; plain
+# "bf16x6" runs inference on the 16x16x32 kernel where that exists (uses_x6w) -- same arithmetic, other summation order
+PRECISIONS = {"fp32": 0, "fp16x3": 1, "bf16x3": 2, "bf16x6": 3, "bf16x6_32": 3}
+X6_PRECISIONS = ("bf16x6", "bf16x6_32")
+X6W_MAX_CHANNELS = 64     # ins_num + 1 up to which the 16x16x32 inference kernel is used (csrc/field_fwd_x6w.hip)
+
+
+def uses_x6w(ins_num: int, precision: str = "bf16x6") -> bool:
+    """True when inference in `precision` runs on the v_mfma_f32_16x16x32_bf16 kernel (and reads the "x6w" blob)."""
+    return precision == "bf16x6" and ins_num + 1 <= X6W_MAX_CHANNELS
+
+
+def inference_precision_code(precision: str, ins_num: int) -> int:
+    """`precision` argument of the C entry points that run the inference chain (dmn_render_rays) for the blob
+    ``DM_NeRF.blob(precision)``: DMN_PREC_BF16X6W where bf16x6 inference runs on the 16x16x32 kernel."""
+    return 4 if uses_x6w(ins_num, precision) else precision_code(precision)
+
+
+def save_blob_name(precision: str) -> str:
+    """DM_NeRF.blob() name of the blob the SAVING forward and the fused kernels of `precision` read."""
+    return "bf16x6_32" if precision in X6_PRECISIONS else precision
 X3_PRECISIONS = ("fp16x3", "bf16x3")        # two-way split kernels (22 / 16 operand bits); "bf16x6" carries all 24
 # What dm_nerf(), the image loop and DM_NeRF.forward() run when the caller does not say (args.precision / model.precision):
 # fp32-grade products on the bf16 matrix pipe -- every fp32 operand enters the products with all of its 24 significand
@@ -158,6 +178,16 @@ def pack_index_x6(ins_num: int, device) -> torch.Tensor:
     return torch.from_numpy(idx).to(device)
 
 
+def pack_index_x6w(ins_num: int, device) -> torch.Tensor:
+    lib = load()
+    n = lib.dmn_field_pack_index_x6_len(ins_num)          # same length: the x6w blob holds the same bytes in another order
+    if n < 0:
+        raise ValueError(f"ins_num={ins_num} unsupported (ins_num + 1 must be <= {MAX_INS_CHANNELS})")
+    idx = np.empty(n, dtype=np.int32)
+    check(lib.dmn_field_pack_index_x6w(ins_num, idx.ctypes.data), "dmn_field_pack_index_x6w")
+    return torch.from_numpy(idx).to(device)
+
+
 def pack_blob_x6(flat_params: torch.Tensor, index: torch.Tensor, ins_num: int) -> torch.Tensor:
     """Blob of the full-precision bf16 kernel: every weight as its exact hi / mid / lo bf16 planes."""
     _dev(flat_params, "flat_params")
@@ -236,9 +266,10 @@ def field_rays(rays_o: torch.Tensor, rays_d: torch.Tensor, z: torch.Tensor, blob
         if precision == "fp32":
             check(load().dmn_field_fwd_rays(ptr(rays_o), ptr(rays_d), ptr(zz), stride, n, s, ptr(blob), ins_num,
                                             ptr(raw), current_stream()), "dmn_field_fwd_rays")
-        elif precision == "bf16x6":
-            check(load().dmn_field_fwd_rays_x6(ptr(rays_o), ptr(rays_d), ptr(zz), stride, n, s, ptr(blob), ins_num,
-                                               int(sigma_only), ptr(raw), current_stream()), "dmn_field_fwd_rays_x6")
+        elif precision in X6_PRECISIONS:
+            fn = load().dmn_field_fwd_rays_x6w if uses_x6w(ins_num, precision) else load().dmn_field_fwd_rays_x6
+            check(fn(ptr(rays_o), ptr(rays_d), ptr(zz), stride, n, s, ptr(blob), ins_num, int(sigma_only), ptr(raw),
+                     current_stream()), "dmn_field_fwd_rays_x6")
         else:
             fn = load().dmn_field_fwd_rays_x3_sigma if sigma_only else load().dmn_field_fwd_rays_x3
             check(fn(ptr(rays_o), ptr(rays_d), ptr(zz), stride, n, s, ptr(blob), ins_num, precision_code(precision),
@@ -309,7 +340,7 @@ def field_rays_save(rays_o: torch.Tensor, rays_d: torch.Tensor, z: torch.Tensor,
                     ins_num: int, precision: str = "fp32") -> Tuple[torch.Tensor, torch.Tensor]:
     """Field forward that also writes the save record the backward kernels read: exact fp32 ("fp32"), fp32-grade products
     on the bf16 pipe ("bf16x6") or three bf16 MFMAs per product ("bf16x3"), each with the blob of that precision."""
-    if precision not in ("fp32", "bf16x6", "bf16x3"):
+    if precision not in ("fp32", "bf16x6", "bf16x6_32", "bf16x3"):
         raise ValueError("the saving forward runs in 'fp32', 'bf16x6' or 'bf16x3'")
     n = rays_o.shape[0]
     rays_o = _dev(rays_o, "rays_o").contiguous()
@@ -322,7 +353,7 @@ def field_rays_save(rays_o: torch.Tensor, rays_d: torch.Tensor, z: torch.Tensor,
         if precision == "fp32":
             check(load().dmn_field_fwd_rays_save(ptr(rays_o), ptr(rays_d), ptr(zz), stride, n, s, ptr(blob), ins_num,
                                                  ptr(raw), ptr(save), current_stream()), "dmn_field_fwd_rays_save")
-        elif precision == "bf16x6":
+        elif precision in X6_PRECISIONS:        # blob: DM_NeRF.blob(save_blob_name(precision))
             check(load().dmn_field_fwd_rays_x6_save(ptr(rays_o), ptr(rays_d), ptr(zz), stride, n, s, ptr(blob), ins_num,
                                                     ptr(raw), ptr(save), current_stream()), "dmn_field_fwd_rays_x6_save")
         else:
@@ -409,9 +440,9 @@ def field_embedded(embedded: torch.Tensor, blob: torch.Tensor, ins_num: int, pre
     if precision == "fp32":
         check(load().dmn_field_fwd_embedded(ptr(flat), flat.shape[0], ptr(blob), ins_num, ptr(raw),
                                             current_stream()), "dmn_field_fwd_embedded")
-    elif precision == "bf16x6":
-        check(load().dmn_field_fwd_embedded_x6(ptr(flat), flat.shape[0], ptr(blob), ins_num, ptr(raw),
-                                               current_stream()), "dmn_field_fwd_embedded_x6")
+    elif precision in X6_PRECISIONS:
+        fn = load().dmn_field_fwd_embedded_x6w if uses_x6w(ins_num, precision) else load().dmn_field_fwd_embedded_x6
+        check(fn(ptr(flat), flat.shape[0], ptr(blob), ins_num, ptr(raw), current_stream()), "dmn_field_fwd_embedded_x6")
     else:
         check(load().dmn_field_fwd_embedded_x3(ptr(flat), flat.shape[0], ptr(blob), ins_num,
                                                precision_code(precision), ptr(raw), ptr(status_word(raw.device)),
@@ -447,7 +478,7 @@ def fused_supported(n_samples: int, n_importance: int, ins_num: int, precision: 
     """Whether ``render_fused`` covers this configuration: bf16 / fp16 matrix-pipe kernels, 64-sample passes, and the coarse
     launch's resampling scratch -- (4 * n_samples + n_importance) floats per ray -- inside its 8 KB of LDS (the same
     bound ``dmn_field_composite_x3`` checks; beyond it the image loop takes the chained kernels)."""
-    return (precision in X3_PRECISIONS + ("bf16x6",) and n_samples % 64 == 0 and (n_samples + n_importance) % 64 == 0
+    return (precision in X3_PRECISIONS + X6_PRECISIONS and n_samples % 64 == 0 and (n_samples + n_importance) % 64 == 0
             and n_samples >= 64 and 0 <= n_importance <= 1024 and 4 * n_samples + n_importance <= FUSED_SCRATCH_FLOATS
             and ins_num + 1 <= MAX_INS_CHANNELS)
 

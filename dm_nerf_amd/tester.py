@@ -66,7 +66,7 @@ def render_image(position_embedder, view_embedder, model_coarse, model_fine, c2w
             z = z_val_sample(n, args.near, args.far, args.N_samples)
             if fused:
                 out = ops.render_fused(rays_o[start:start + n], rays_d[start:start + n], z,
-                                       model_coarse.blob(precision), model_fine.blob(precision), model_fine.ins_num,
+                                       model_coarse.blob(ops.save_blob_name(precision)), model_fine.blob(ops.save_blob_name(precision)), model_fine.ins_num,
                                        precision, int(args.N_importance), coarse_sigma_only=image_only,
                                        u=_unit_linspace(int(args.N_importance), rays_o.device.index))   # det=True
             else:

@@ -53,7 +53,8 @@ class FieldFnLibrary(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rays_o, rays_d, z, model, precision, *params):
-        raw = ops.field_rays(rays_o, rays_d, z, model.blob(precision), model.ins_num, precision)
+        kernel = ops.save_blob_name(precision)      # the kernel family FieldFn's saving forward runs (bf16x6: 32x32x16)
+        raw = ops.field_rays(rays_o, rays_d, z, model.blob(kernel), model.ins_num, kernel)
         ctx.save_for_backward(rays_o, rays_d, z.contiguous())
         ctx.names = [n for n, _ in model.named_parameters()]
         ctx.params = params

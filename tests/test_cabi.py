@@ -87,8 +87,9 @@ def test_inline_asm_accumulator_reads_keep_their_distance_from_the_producing_mfm
     """field_x3.h / field_x6.h read finished accumulator tiles with inline asm (v_accvgpr_read_b32) so that they stay in
     their AGPRs; the compiler inserts no MFMA -> VALU hazard wait states for inline asm, so the distance is guaranteed
     by construction (x3: one full k-step on the other tile; x6: 6 x (NT - 1) MFMAs) and checked here on the generated
-    ISA of every kernel that does it -- the default (bf16x6) field kernel and the fused kernel included.  The x6 field
-    kernels must also stay lean: no scratch, no SGPRs parked in vector-register lanes (tools/check_acc_hazard.py)."""
+    ISA of every kernel that does it -- the default (bf16x6, 16x16x32) field kernel, its 32x32x16 sibling, the bf16x6
+    backward-data kernel and the fused kernel included.  The x6 kernels must also stay lean: no scratch (its traffic
+    evicts the weight stream from the L2), no SGPRs parked in vector-register lanes (tools/check_acc_hazard.py)."""
     import shutil
     import subprocess
     import sys
@@ -100,6 +101,7 @@ def test_inline_asm_accumulator_reads_keep_their_distance_from_the_producing_mfm
     from dm_nerf_amd.build import FLAGS
     flags = [f for f in FLAGS if f not in ("-shared", "-fPIC")]
     sources = {"field_bwd_x3.hip": [], "field_fwd_x3.hip": [], "field_fwd_x6.hip": ["--lean", "field_fwd_x6_kernel"],
+               "field_fwd_x6w.hip": ["--lean", "field_fwd_x6w_kernel"], "field_bwd_x6.hip": ["--lean", "field_bwd_data_x6_kernel"],
                "field_fused_x3.hip": []}
 
     def check(src):
@@ -109,11 +111,13 @@ def test_inline_asm_accumulator_reads_keep_their_distance_from_the_producing_mfm
         return subprocess.run([sys.executable, os.path.join(root, "tools", "check_acc_hazard.py"), out, *sources[src]],
                               capture_output=True, text=True)
 
-    with ThreadPoolExecutor(max_workers=4) as pool:
+    with ThreadPoolExecutor(max_workers=6) as pool:
         results = dict(zip(sources, pool.map(check, sources)))
     for src, res in results.items():
         assert res.returncode == 0, src + "\n" + res.stdout + res.stderr
         assert "accumulator reads" in res.stdout
     # every instantiation of the default kernel was seen (4 head widths x inference / saving), and of the fused x6 network
     assert results["field_fwd_x6.hip"].stdout.count("field_fwd_x6_kernel") == 8
+    assert results["field_fwd_x6w.hip"].stdout.count("field_fwd_x6w_kernel") == 3      # the default inference kernel: 1, 2, 4 tiles
+    assert results["field_bwd_x6.hip"].stdout.count("field_bwd_data_x6_kernel") == 4
     assert results["field_fused_x3.hip"].stdout.count("NetX6") == 4

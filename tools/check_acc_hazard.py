@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """Static check of the split-precision kernels' ISA (x3, x6 and the fused kernel's instantiations of both).
 
-1. Every v_accvgpr_read of an accumulator register must be separated from the last MFMA that wrote its tuple by >= 11
-   wait states (instructions count 1, s_nop N counts N + 1, an MFMA in between 8) -- the inline-asm reads of field_x3.h /
-   field_x6.h are not covered by the compiler's hazard recognizer.  Rolled loops are walked twice (every backward branch
+1. Every INLINE-ASM v_accvgpr_read of an accumulator register (between ;;#ASMSTART / ;;#ASMEND: the reads of field_x3.h /
+   field_x6.h / field_fwd_x6w.hip, which the compiler's hazard recognizer does not cover) must be separated from the last
+   MFMA that wrote its tuple by as many wait states as the compiler itself leaves behind that MFMA shape: 11 for the
+   16-pass 32x32x16 forms, 8 for the 8-pass 16x16x32 form (instructions count 1, s_nop N counts N + 1, an MFMA in
+   between 8).  Reads the compiler generated are its own business and are not held against these numbers.  Rolled loops are walked twice (every backward branch
    is followed once), so a read at the top of a loop body is also held against the MFMAs at its bottom.
 2. --lean KERNEL_SUBSTRING (repeatable): kernels whose name contains it must have no scratch
    (.amdhsa_private_segment_fixed_size 0) and no v_writelane / v_readlane SGPR parking (the 580-writelane regression of
@@ -14,7 +16,10 @@ import re
 import sys
 
 KERNEL_TAGS = ("x3_kernel", "x6_kernel", "x6w_kernel")
-MIN_WAIT_STATES = 11
+
+
+def min_wait_states(mfma: str) -> int:
+    return 8 if "16x16x32" in mfma else 11
 
 
 def kernel_bodies(lines):
@@ -27,6 +32,9 @@ def kernel_bodies(lines):
             s = l.strip()
             if s.startswith('.Lfunc_end'):
                 break
+            if s.startswith(';;#ASMSTART') or s.startswith(';;#ASMEND'):
+                body.append((None, s))          # markers: inline-asm reads are told from the compiler's own
+                continue
             if not s or s.startswith(';'):
                 continue
             if s.split()[0].endswith(':'):
@@ -57,22 +65,28 @@ def walk(body):
 
 
 def wait_states(ins):
+    if ins.startswith(';'):
+        return 0
     if ins.startswith('s_nop'):
         return int(ins.split()[1]) + 1
     return 8 if ins.startswith('v_mfma') else 1
 
 
 def check_reads(order):
-    last, worst, reads = {}, 10 ** 9, 0
+    """(inline-asm reads seen, smallest margin = wait states minus what the producing MFMA shape needs)."""
+    last, worst, reads, in_asm = {}, 10 ** 9, 0, False
     for j, l in enumerate(order):
-        m = re.match(r'v_mfma\S* a\[(\d+):(\d+)\]', l)
+        if l.startswith(';;#ASM'):
+            in_asm = l.startswith(';;#ASMSTART')
+            continue
+        m = re.match(r'(v_mfma\S*) a\[(\d+):(\d+)\]', l)
         if m:
-            last[(int(m.group(1)), int(m.group(2)))] = j
+            last[(int(m.group(2)), int(m.group(3)))] = (j, m.group(1))
             continue
         m = re.match(r'v_accvgpr_read_b32 v\d+, a(\d+)', l)
-        if m:
+        if m and in_asm:
             a = int(m.group(1))
-            for (lo, hi), jw in last.items():
+            for (lo, hi), (jw, shape) in last.items():
                 if lo <= a <= hi:
                     reads += 1
                     ws = 0
@@ -80,7 +94,7 @@ def check_reads(order):
                         ws += wait_states(x)
                         if ws >= 4096:          # far enough: do not sum kernel-long stretches for every read
                             break
-                    worst = min(worst, ws)
+                    worst = min(worst, ws - min_wait_states(shape))
     return reads, worst
 
 
@@ -104,14 +118,14 @@ def main(argv):
         reads, worst = check_reads(walk(body))
         lanes = sum(1 for _, s in body if s.startswith(('v_writelane', 'v_readlane')))
         if reads:
-            print(f"{name[:100]}  accumulator reads {reads}, fewest wait states after the producing MFMA: {worst}; "
+            print(f"{name[:100]}  accumulator reads {reads}, smallest margin over the producing MFMA's wait states: {worst}; "
                   f"scratch {scratch.get(name, '?')} B, v_writelane/v_readlane {lanes}")
             worst_all = worst if worst_all is None else min(worst_all, worst)
         if any(t in name for t in lean):
             if scratch.get(name) != 0 or lanes != 0:
                 print(f"NOT LEAN: {name[:100]}: scratch {scratch.get(name)} B, v_writelane/v_readlane {lanes}")
                 ok = False
-    return 0 if ok and worst_all is not None and worst_all >= MIN_WAIT_STATES else 1
+    return 0 if ok and worst_all is not None and worst_all >= 0 else 1
 
 
 if __name__ == "__main__":

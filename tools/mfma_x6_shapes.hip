@@ -17,6 +17,9 @@
 #ifndef SCALAR_SUB
 #define SCALAR_SUB 0
 #endif
+#ifndef CHAINS
+#define CHAINS 2
+#endif
 #ifndef INTERLEAVE
 #define INTERLEAVE 0
 #endif
@@ -156,7 +159,8 @@ __device__ __forceinline__ void layer32(Ctx& c, f32x16* out, const f32x16* in) {
 // ---- SHAPE 1: the same layer on 16x16x32: 8 k-steps of 32 x 16 feature tiles x 2 point tiles ---------------------------
 // accumulators acc[p][t] (point tile p, feature tile t), 4 registers each; the B operand of k-step ks for point tile p is
 // built from tiles 2 ks and 2 ks + 1 of the finished set (4 + 4 values per lane: the k order is a permutation the weight
-// packing absorbs, as in field_layout.h)
+// packing absorbs, as in field_layout.h).  CHAINS: dependent accumulation chains in flight: 2 = the two point tiles of
+// one feature tile (12 MFMAs per group), 4 = two feature tiles at a time (24 MFMAs per double group, issued round-robin)
 __device__ __forceinline__ void layer16(Ctx& c, f32x4 (*out)[16], const f32x4 (*in)[16]) {
 #pragma unroll
   for (int p = 0; p < 2; ++p)
@@ -172,46 +176,59 @@ __device__ __forceinline__ void layer16(Ctx& c, f32x4 (*out)[16], const f32x4 (*
   };
 #pragma unroll
   for (int q = 0; q < 8; ++q) build_pair(0, q, bh, bm, bl);
-  frag ah[2], am[2], al[2];
+  constexpr int TG = CHAINS == 4 ? 2 : 1;      // feature tiles per group
+  frag ah[2][TG], am[2][TG], al[2][TG];
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) {
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int gi = t, ar = t & 1;           // 16 groups = one stage per k-step
+    for (int t = 0; t < 16; t += TG) {
+      const int gi = t, ar = (t / TG) & 1;           // 16 tiles = one stage per k-step
       if (gi == 0) {
         stage_begin(c);
-        ah[ar] = *reinterpret_cast<const frag*>(c.buf);
-        am[ar] = *reinterpret_cast<const frag*>(c.buf + 1024);
-        al[ar] = *reinterpret_cast<const frag*>(c.buf + 2048);
+#pragma unroll
+        for (int u = 0; u < TG; ++u) {
+          ah[ar][u] = *reinterpret_cast<const frag*>(c.buf + (3 * u) * 1024);
+          am[ar][u] = *reinterpret_cast<const frag*>(c.buf + (3 * u + 1) * 1024);
+          al[ar][u] = *reinterpret_cast<const frag*>(c.buf + (3 * u + 2) * 1024);
+        }
       }
-      if (gi + 1 < 16) {
-        ah[ar ^ 1] = *reinterpret_cast<const frag*>(c.buf + (3 * (gi + 1)) * 1024);
-        am[ar ^ 1] = *reinterpret_cast<const frag*>(c.buf + (3 * (gi + 1) + 1) * 1024);
-        al[ar ^ 1] = *reinterpret_cast<const frag*>(c.buf + (3 * (gi + 1) + 2) * 1024);
+      if (gi + TG < 16) {
+#pragma unroll
+        for (int u = 0; u < TG; ++u) {
+          ah[ar ^ 1][u] = *reinterpret_cast<const frag*>(c.buf + (3 * (gi + TG + u)) * 1024);
+          am[ar ^ 1][u] = *reinterpret_cast<const frag*>(c.buf + (3 * (gi + TG + u) + 1) * 1024);
+          al[ar ^ 1][u] = *reinterpret_cast<const frag*>(c.buf + (3 * (gi + TG + u) + 2) * 1024);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
+#define PROD(A, B)                                                                                     \
+  _Pragma("unroll") for (int u = 0; u < TG; ++u) _Pragma("unroll") for (int p = 0; p < 2; ++p)          \
+      out[p][t + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ar][u], B[p], out[p][t + u], 0, 0, 0);
+#if CHAINS == 4      // round-robin over the four chains, product by product
+      PROD(al, bh) PROD(ah, bl) PROD(am, bm) PROD(am, bh) PROD(ah, bm) PROD(ah, bh)
+#else
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
-        out[p][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ar], bh[p], out[p][t], 0, 0, 0);
-        out[p][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ar], bl[p], out[p][t], 0, 0, 0);
-        out[p][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[ar], bm[p], out[p][t], 0, 0, 0);
-        out[p][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[ar], bh[p], out[p][t], 0, 0, 0);
-        out[p][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ar], bm[p], out[p][t], 0, 0, 0);
-        out[p][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ar], bh[p], out[p][t], 0, 0, 0);
+        out[p][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ar][0], bh[p], out[p][t], 0, 0, 0);
+        out[p][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ar][0], bl[p], out[p][t], 0, 0, 0);
+        out[p][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[ar][0], bm[p], out[p][t], 0, 0, 0);
+        out[p][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[ar][0], bh[p], out[p][t], 0, 0, 0);
+        out[p][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ar][0], bm[p], out[p][t], 0, 0, 0);
+        out[p][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ar][0], bh[p], out[p][t], 0, 0, 0);
+#if CHAINS == 1      // one dependent chain at a time: the six products of a point tile back to back
+        __builtin_amdgcn_sched_barrier(0);
+#endif
       }
-      if (gi < 12) piece(c, gi);
+#endif
+#undef PROD
+#pragma unroll
+      for (int u = 0; u < TG; ++u)
+        if (gi + u < 12) piece(c, gi + u);
       if (ks + 1 < 8) {
 #pragma unroll
         for (int q = 0; q < 8; ++q)
-          if (q * 2 == t) build_pair(ks + 1, q, nh, nm, nl);      // one value pair per two groups
+          if (q * 2 >= t && q * 2 < t + TG) build_pair(ks + 1, q, nh, nm, nl);      // one value pair per two tiles
       }
-#if INTERLEAVE      // at most INTERLEAVE vector instructions between two MFMAs of the group
-#pragma unroll
-      for (int i = 0; i < 12; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, INTERLEAVE, 0);
-      }
-#endif
     }
 #pragma unroll
     for (int p = 0; p < 2; ++p) { bh[p] = nh[p]; bm[p] = nm[p]; bl[p] = nl[p]; }

@@ -215,8 +215,10 @@ def field_roofline(profile, precision: str, elapsed: float):
     k = MFMA_PRODUCTS[precision]
     pipe = PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_16BIT_MFMA_TFLOPS
     name = {"fp32": "field_fwd_kernel<1> (fused encodings + 8x256 field, exact fp32 MFMA v_mfma_f32_32x32x2_f32)",
-            "bf16x6": "field_fwd_x6_kernel<1> (fused encodings + 8x256 field; fp32 operands split exactly into 3 bf16 planes, "
-                      "every fp32 product = 6 v_mfma_f32_32x32x16_bf16 products, fp32 accumulate)"}.get(
+            "bf16x6": ("field_fwd_x6w_kernel (fused encodings + 8x256 field; fp32 operands split exactly into 3 bf16 planes, "
+                       "every fp32 product = 6 v_mfma_f32_16x16x32_bf16 products, fp32 accumulate)" if ops.uses_x6w(INS_NUM)
+                       else "field_fwd_x6_kernel (fused encodings + 8x256 field; fp32 operands split exactly into 3 bf16 "
+                            "planes, every fp32 product = 6 v_mfma_f32_32x32x16_bf16 products, fp32 accumulate)")}.get(
         precision, f"field_fwd_x3_kernel<{precision}> (fused encodings + 8x256 field; every fp32 product = 3 16-bit MFMA "
                    "products on hi/lo splits, fp32 accumulate)")
     out = {"kernel": name, "bound": "mfma", "achieved": tflops, "peak": pipe / k, "unit": "TFLOP/s", "frac": tflops * k / pipe,

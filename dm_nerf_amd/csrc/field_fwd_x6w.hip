@@ -39,8 +39,9 @@ struct SrcTilesW {                       // the accumulators of the layer before
   const f32x4 (*a)[NT_IN];
   __device__ __forceinline__ float operator()(int p, int ks, int j) const { return acc_read1(a[p][2 * ks + (j >> 2)][j & 3]); }
 };
-// The encodings, read where they are consumed out of the exchange area in LDS (see the kernel): channel CH0 + 32 ks + 8 q + j
-// of point 16 p + n; `lane_base` = exchange row 8 q, column n of this wave.  Channels past the end are zero padding.
+// The encodings, read where they are consumed out of the exchange area in LDS (see the kernel): channel 32 ks + 8 q + j of
+// the CHANNELS channels that start at exchange row CH0, for point 16 p + n; `lane_base` = exchange row 8 q, column n of
+// this wave.  Channels past the end are zero padding (never the neighbouring rows' contents).
 constexpr int kXchRow = 33;                            // floats per channel row of the exchange: 32 points + 1 (banks)
 template <int CH0, int CHANNELS>
 struct SrcXch {
@@ -182,7 +183,7 @@ __device__ __forceinline__ bool x6w_network(Ctx6& c, const float* cst, const flo
                                             bool sigma_only, float (&sigma)[2], float (&rgb)[2][3], f32x4 (&acc3)[2][T16]) {
   f32x4 accA[2][16], accB[2][16];
   const SrcXch<0, kPosCh> s_pe{xch_lane, q};
-  const SrcXch<kPosCh, kPosCh + kDirCh> s_qe{xch_lane, q};
+  const SrcXch<kPosCh, kDirCh> s_qe{xch_lane, q};
   const SrcTilesW<16> s_a{accA}, s_b{accB};
   const float* const b8 = cst + kConstBias8 + 4 * q;
 

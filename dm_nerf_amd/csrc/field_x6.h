@@ -44,6 +44,9 @@ typedef P6::frag frag;
 #ifndef DMN_X6_ORDER
 #define DMN_X6_ORDER 0
 #endif
+#ifndef DMN_X6_SCALAR_SUB
+#define DMN_X6_SCALAR_SUB 1
+#endif
 #ifndef DMN_X6_NINE
 #define DMN_X6_NINE 0
 #endif
@@ -135,10 +138,24 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, frag& fh, frag& 
   typedef P6::float2v float2v;
   const float2v x = {x0, x1};
   const pair hp = __builtin_convertvector(x, pair);
+#if DMN_X6_SCALAR_SUB   // four v_sub_f32 instead of two v_pk_add_f32 (a packed-f32 instruction beside MFMAs costs ~13 cycles more)
+  const float2v wh = P6::widen(hp);
+  float a0, a1, b0, b1;
+  asm("v_sub_f32 %0, %1, %2" : "=v"(a0) : "v"(x0), "v"(wh[0]));
+  asm("v_sub_f32 %0, %1, %2" : "=v"(a1) : "v"(x1), "v"(wh[1]));
+  const float2v r1 = {a0, a1};
+  const pair mp = __builtin_convertvector(r1, pair);
+  const float2v wm = P6::widen(mp);
+  asm("v_sub_f32 %0, %1, %2" : "=v"(b0) : "v"(a0), "v"(wm[0]));
+  asm("v_sub_f32 %0, %1, %2" : "=v"(b1) : "v"(a1), "v"(wm[1]));
+  const float2v r2 = {b0, b1};
+  const pair lp = __builtin_convertvector(r2, pair);
+#else
   const float2v r1 = x - P6::widen(hp);
   const pair mp = __builtin_convertvector(r1, pair);
   const float2v r2 = r1 - P6::widen(mp);
   const pair lp = __builtin_convertvector(r2, pair);
+#endif
   fh[j] = hp[0]; fh[j + 1] = hp[1];
   fm[j] = mp[0]; fm[j + 1] = mp[1];
   fl[j] = lp[0]; fl[j + 1] = lp[1];

@@ -113,8 +113,90 @@ def train_step(i: int, batch_rays, target_rgb, nerf, z_vals_coarse, optimizer, l
     names = list(terms) + ["total"]                                 # one read-back for all of them
     vals = torch.stack([v.detach().float().reshape(()) for v in terms.values()] + [total.detach().float()]).tolist()
     report = dict(zip(names, vals))
+    # With the Hungarian step on the device (assign="device") nothing waits for the loss head's status words, and a label
+    # outside [0, ins_num) or a failed assignment shows up as non-finite instance terms with zero gradients (the host
+    # form raises at once, as the reference's indexing does): this read-back is the first point that waits -- fail there.
+    bad = [k for k in ("ins_coarse", "ins_fine") if k in report and not math.isfinite(report[k])]
+    if bad:
+        raise ValueError(f"instance-matching loss is not finite ({', '.join(bad)}): a label outside [0, ins_num) or a failed "
+                         "device-side assignment (assign='device' reports neither at the call; assign='host' raises there)")
     report["psnr_fine"] = -10.0 * math.log10(report["rgb_fine"]) if report["rgb_fine"] > 0 else float("inf")
     return report
+
+
+class GraphedTrainStep:
+    """One optimisation step captured in a hipGraph (``torch.cuda.CUDAGraph``): forward of both networks, the loss heads
+    (``ins_loss`` must be sync-free: ``instance_loss(..., assign="device")``), the hand-written backward, Adam and the
+    learning-rate decay replay as ONE host call instead of ~85 kernel launches.  What ``train_step(report=False)`` does
+    per iteration (train_dmsr.py:32-72), with the state that changes from step to step held in device tensors:
+
+      step.rays [2, N, 3], step.target [N, 3]   static input buffers: fill them in place (``copy_``, or let the selector
+                                                kernels write there), then call ``step()``
+      step.lr, step.iteration                   learning rate (decayed in the graph AFTER the update, as :68-72) and the
+                                                iteration count it is computed from
+      step.terms                                the loss terms of the last replay (0-dim device tensors; read them when
+                                                you would print them -- that read is the only wait for the device)
+
+    The constructor runs ``warmup`` eager steps (they are real steps: weights move, ``iteration`` counts them) so that
+    every lazily built table exists before the capture, then captures one.  The optimizer is torch's Adam with
+    ``capturable=True`` and a tensor learning rate (``step.optimizer``); checkpoint it as usual.  Labels closed over by
+    ``ins_loss`` are read from their tensor at every replay (their class table is rebuilt inside the graph)."""
+
+    def __init__(self, batch_rays, target_rgb, nerf, z_vals_coarse, lrate: float = 5e-4, lrate_decay: int = 500,
+                 ins_loss: Optional[Callable] = None, penalizer: Optional[Callable] = None, first_iteration: int = 0,
+                 warmup: int = 2):
+        position_embedder, view_embedder, model_coarse, model_fine, args = nerf
+        dev = batch_rays.device
+        self.rays, self.target = batch_rays.clone(), target_rgb.clone()
+        self.lr = torch.tensor(float(decayed_lrate(first_iteration, lrate, lrate_decay)), device=dev)
+        self.iteration = torch.tensor(float(first_iteration), device=dev)
+        self.optimizer = torch.optim.Adam(list(model_coarse.parameters()) + list(model_fine.parameters()), lr=self.lr,
+                                          betas=(0.9, 0.999), capturable=True)
+        scale = 1.0 / (lrate_decay * 1000.0)
+        tenth = torch.tensor(0.1, device=dev)
+
+        def body():
+            out = dm_nerf(self.rays, position_embedder, view_embedder, model_coarse, model_fine, z_vals_coarse, args)
+            terms = {"rgb_coarse": _MseFn.apply(out["rgb_coarse"], self.target),
+                     "rgb_fine": _MseFn.apply(out["rgb_fine"], self.target)}
+            total = terms["rgb_fine"] + terms["rgb_coarse"]
+            empty = None
+            if penalizer is not None:
+                empty = (penalizer(out["raw_coarse"], out["z_vals_coarse"], out["depth_coarse"]),
+                         penalizer(out["raw_fine"], out["z_vals_fine"], out["depth_fine"]))
+            if ins_loss is not None:
+                many = getattr(ins_loss, "many", None)
+                if many is not None:
+                    terms["ins_coarse"], terms["ins_fine"] = many([out["ins_coarse"], out["ins_fine"]])
+                else:
+                    terms["ins_coarse"], terms["ins_fine"] = ins_loss(out["ins_coarse"]), ins_loss(out["ins_fine"])
+                total = total + terms["ins_coarse"] + terms["ins_fine"]
+            if empty is not None:
+                terms["empty_coarse"], terms["empty_fine"] = empty
+                total = total + terms["empty_coarse"] + terms["empty_fine"]
+            self.optimizer.zero_grad(set_to_none=True)
+            total.backward()
+            self.optimizer.step()
+            self.lr.copy_(lrate * torch.pow(tenth, self.iteration * scale))      # lrate * 0.1 ** (i / (decay * 1000)), :68-72
+            self.iteration += 1.0
+            return {**{k: v.detach() for k, v in terms.items()}, "total": total.detach()}
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        from . import evaluator
+        evaluator._LABEL_PREP.clear()           # the labels' class table is rebuilt inside the graph, at every replay
+        self.optimizer.zero_grad(set_to_none=True)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.terms = body()
+
+    def __call__(self) -> Dict[str, torch.Tensor]:
+        self.graph.replay()
+        return self.terms
 
 
 def checkpoint_dict(i: int, model_coarse, model_fine, optimizer) -> dict:

@@ -10,6 +10,8 @@ of the expected tensor):
     reference, BASELINE.md section 2: inverse-CDF sampling divides 1e-7 cdf differences by bin masses
     down to 1e-5).  The stage-wise tests feed the golden depths in and require 1e-4.
 """
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -1226,6 +1228,86 @@ def test_sharded_instance_loss_stops_every_shard_on_a_label_out_of_range(fused):
     # and both shards issued the same reductions before they stopped (the tensor-operation form reads the flag right
     # behind the first one, the kernels' form with its one read-back behind the third)
     assert clean.calls == len(rec.own) == (3 if fused else 1)
+
+
+def test_device_side_assignment_surfaces_a_label_out_of_range_at_the_loss_read_back():
+    """Ray-sharded training with assign="device" never waits for the loss head's status words: a label outside
+    [0, ins_num] (the sharded path's label bins) gives non-finite instance terms and zero gradients from that head
+    instead of the ValueError the host form raises at the call.  The step's loss read-back
+    (trainer.train_step(report=True)) is the first point that waits for the device: it raises."""
+    from dm_nerf_amd import trainer
+    n, ins_num = 64, 13
+    pos, view, coarse, fine, args = nets(ins_num, 0, 1)
+    coarse.train(); fine.train()
+    o, d, _, _ = cases.path_rays(n, seed=29)
+    targs = SimpleNamespace(**{**vars(args), "perturb": 1.0, "is_train": True})
+    _, labels = cases.criterion_case(n, ins_num, (0, 2, 3, 7, 12), 317)
+    bad = labels.copy()
+    bad[5] = ins_num + 4
+    z = dm.z_val_sample(n, cases.NEAR, cases.FAR, 64)
+    target = G(np.random.default_rng(3).uniform(0, 1, (n, 3)).astype(np.float32))
+    opt = trainer.make_optimizer(coarse, fine)
+    one_shard = lambda tag, t: t                                      # the sharded code path on a world of one
+    step = lambda lab, report: trainer.train_step(
+        0, G(np.stack([o, d], 0)), target, (pos, view, coarse, fine, targs), z, opt,
+        ins_loss=trainer.instance_loss(torch.from_numpy(lab).to(DEV), ins_num, assign="device", reduce=one_shard),
+        report=report)
+    good = step(labels, True)
+    assert math.isfinite(good["ins_fine"]) and math.isfinite(good["total"])
+    quiet = step(bad, False)                                          # no read-back: nothing can raise here
+    assert not math.isfinite(float(quiet["ins_fine"]))
+    with pytest.raises(ValueError, match="label outside"):
+        step(bad, True)
+    with pytest.raises(ValueError):                                          # the host form raises at the call
+        trainer.train_step(0, G(np.stack([o, d], 0)), target, (pos, view, coarse, fine, targs), z, opt,
+                           ins_loss=trainer.instance_loss(torch.from_numpy(bad).to(DEV), ins_num, assign="host",
+                                                          reduce=one_shard))
+
+
+def test_graph_captured_training_step_equals_the_eager_steps():
+    """trainer.GraphedTrainStep: the whole step (both forwards, loss heads with the device-side Hungarian step, hand-written
+    backward, Adam, learning-rate decay) replayed from one hipGraph against the same number of eager train_step() calls
+    from the same start: same loss terms and weights (Adam's capturable form differs from the default one by rounding),
+    the decayed learning rate of train_dmsr.py:68-72, inputs read from the static buffers at every replay."""
+    from dm_nerf_amd import trainer
+    n, ins_num, lrate, decay = 256, 13, 5e-4, 1
+    o, d, _, _ = cases.path_rays(n, seed=37)
+    rays = G(np.stack([o, d], 0))
+    rng = np.random.default_rng(5)
+    target = G(rng.uniform(0, 1, (n, 3)).astype(np.float32))
+    labels = torch.from_numpy(rng.integers(0, ins_num, n)).to(DEV)
+    z = dm.z_val_sample(n, cases.NEAR, cases.FAR, 64)
+
+    def fresh():
+        pos, view, coarse, fine, args = nets(ins_num, 0, 1)
+        coarse.train(); fine.train()
+        targs = SimpleNamespace(**{**vars(args), "perturb": 0.0, "is_train": True, "tolerance": 0.05, "deta_w": 0.05})
+        return (pos, view, coarse, fine, targs)
+
+    def heads(nerf):
+        return dict(ins_loss=trainer.instance_loss(labels, ins_num, assign="device"),
+                    penalizer=lambda raw, zz, depth: dm.ins_penalizer(raw, zz, depth, rays[1], nerf[4]))
+
+    eager = fresh()
+    opt = trainer.make_optimizer(eager[2], eager[3], lrate)
+    for i in range(4):
+        last = trainer.train_step(i, rays, target, eager, z, opt, lrate=lrate, lrate_decay=decay, report=False, **heads(eager))
+    graphed = fresh()
+    step = trainer.GraphedTrainStep(rays, target, graphed, z, lrate=lrate, lrate_decay=decay, warmup=2, **heads(graphed))
+    for _ in range(2):                                                       # 2 warm-up steps + the captured one... = 3; one more
+        terms = step()                                                       # replay: steps 3 and 4 (the capture itself runs nothing)
+    assert float(step.iteration) == 4.0
+    assert abs(float(step.lr) - trainer.decayed_lrate(3, lrate, decay)) < 1e-9       # set after step 3 for step 4, as :68-72
+    # (four steps: the two Adam forms differ by rounding from the first update on, and behind the resampler a rounding
+    # moves single depths -- observed 8e-5 on the emptiness term, 1e-5 on the others)
+    for k in last:
+        assert abs(float(terms[k]) - float(last[k])) < 1e-3 * max(1.0, abs(float(last[k]))), (k, float(terms[k]), float(last[k]))
+    for (k, a), b in zip(eager[3].named_parameters(), graphed[3].parameters()):
+        assert float((a - b).abs().max()) < 2e-4 * float(a.abs().max()) + 1e-7, k
+    # the replay reads its inputs from the static buffers: new targets change the colour loss
+    before = float(step()["rgb_fine"])
+    step.target.copy_(1.0 - step.target)
+    assert abs(float(step()["rgb_fine"]) - before) > 1e-3
 
 
 def test_grad_bucket_receives_the_weight_gradients_in_place():

@@ -491,6 +491,130 @@ def test_x6_blob_consumed_in_kernel_order_equals_the_field_to_fp32_rounding(ins_
     assert np.bincount(idx[idx >= 0], minlength=flat.size).min() >= 1
 
 
+# ---------------------------------------------------------------------------------------------
+# "x6w" blob: the same planes for v_mfma_f32_16x16x32_bf16 (csrc/field_layout.h "x6w", csrc/field_fwd_x6w.hip): 16 x 16
+# tiles, 32-deep k-steps, two point tiles per wave, const section in natural feature order.  Lane-exact model of the
+# instruction's operand / accumulator maps: A[i = l & 15][k = 8 (l >> 4) + j], B[k = 8 (l >> 4) + j][n = l & 15],
+# D[i = 4 (l >> 4) + r][n = l & 15].
+# ---------------------------------------------------------------------------------------------
+N16, Q16 = LANE & 15, LANE >> 4
+
+
+class WaveX6W:
+    def __init__(self, cst, planes):
+        self.cst, self.planes = cst, planes
+
+    def layer(self, stage0, n_tiles, slots, bias_off):
+        """slots: per k-step [2 point tiles][8 k-slots][64 lanes] source values.  Returns acc[p][t][16 features][16 points]."""
+        kps = 16 // n_tiles
+        acc = np.zeros((2, n_tiles, 16, 16))
+        for t in range(n_tiles):
+            acc[:, t] = self.cst[bias_off + 16 * t:bias_off + 16 * t + 16][None, :, None]
+        for ks, f in enumerate(slots):
+            for t in range(n_tiles):
+                chunk = (stage0 + ks // kps) * X6_STAGE_CHUNKS + ((ks % kps) * n_tiles + t) * 3
+                A = []
+                for plane in range(3):
+                    a = self.planes[(chunk + plane) * X3_CHUNK:(chunk + plane + 1) * X3_CHUNK].reshape(64, 8)
+                    M = np.zeros((16, 32))
+                    for j in range(8):
+                        M[N16, 8 * Q16 + j] = a[:, j]
+                    A.append(M)
+                ah, am, al = A
+                for p in range(2):
+                    B = []
+                    for b in split3(f[p]):
+                        M = np.zeros((32, 16))
+                        for j in range(8):
+                            M[8 * Q16 + j, N16] = b[j].astype(np.float64)
+                        B.append(M)
+                    Bh, Bm, Bl = B
+                    acc[p, t] += al @ Bh + ah @ Bl + am @ Bm + am @ Bh + ah @ Bm + ah @ Bh
+        return acc
+
+    @staticmethod
+    def slots_of(acc, relu):
+        """k-slots the NEXT layer reads out of these accumulators: k-step ks, slot j of lane (n, q) is register j & 3 of
+        feature tile 2 ks + (j >> 2), i.e. feature 16 (2 ks + (j >> 2)) + 4 q + (j & 3) of point n."""
+        vals = acc.astype(np.float32)
+        if relu:
+            vals = np.maximum(vals, 0)
+        n_tiles = acc.shape[1]
+        out = []
+        for ks in range(n_tiles // 2):
+            f = np.zeros((2, 8, 64), dtype=np.float32)
+            for p in range(2):
+                for j in range(8):
+                    f[p, j] = vals[p, 2 * ks + (j >> 2), 4 * Q16 + (j & 3), N16]
+            out.append(f)
+        return out, vals
+
+
+def simulate_x6w(idx, flat, emb, ins_num):
+    T16 = (ins_num + 1 + 15) // 16
+    T16 = T16 if T16 <= 2 else (4 if T16 <= 4 else (6 if T16 <= 6 else 8))
+    vals = np.where(idx >= 0, flat[np.clip(idx, 0, None)], 0.0).astype(np.float32)
+    cst = vals[:CONST].astype(np.float64)
+    stream = vals[CONST:]
+    hi, mid, lo = split3(stream)
+    plane = (np.arange(stream.size) // X3_CHUNK) % 3
+    w = WaveX6W(cst, np.where(plane == 0, hi, np.where(plane == 1, mid, lo)).astype(np.float64))
+
+    def enc_slots(ch0, channels, n_ksteps):          # channel ch0 + 32 e + 8 q + j of point 16 p + n, zero past the end
+        out = []
+        for e in range(n_ksteps):
+            f = np.zeros((2, 8, 64), dtype=np.float32)
+            for p in range(2):
+                for j in range(8):
+                    c = 32 * e + 8 * Q16 + j
+                    ok = c < channels
+                    f[p, j, ok] = emb[16 * p + N16[ok], ch0 + c[ok]]
+            out.append(f)
+        return out
+
+    pe, qe = enc_slots(0, 63, 2), enc_slots(63, 27, 1)
+    act, _ = WaveX6W.slots_of(w.layer(X6_STAGE["l0"], 16, pe, C_BIAS8), True)
+    for l in range(1, 8):
+        stage0 = X6_STAGE["l1"] + 8 * (l - 1) if l <= 4 else (X6_STAGE["l5"] if l == 5 else X6_STAGE["l6"] + 8 * (l - 6))
+        act, h = WaveX6W.slots_of(w.layer(stage0, 16, act + (pe if l == 5 else []), C_BIAS8 + l * 256), True)
+    # heads in natural feature order: h[p][t][f][n] -> feature 16 t + f
+    h8 = h.reshape(2, 256, 16).astype(np.float64)
+    sigma = np.einsum("pfn,f->pn", h8, cst[C_DENSW:C_DENSW + 256]) + cst[C_DENSB]
+    g, _ = WaveX6W.slots_of(w.layer(X6_STAGE["rgbf"], 16, act, C_BIAS8 + 8 * 256), False)
+    _, r = WaveX6W.slots_of(w.layer(X6_STAGE["rgbh"], 8, g + qe, C_BIAS4), True)
+    r = r.reshape(2, 128, 16).astype(np.float64)
+    rgb = np.stack([np.einsum("pfn,f->pn", r, cst[C_RGBW + c * 128:C_RGBW + c * 128 + 128]) + cst[C_RGBB + c] for c in range(3)], 1)
+    e, _ = WaveX6W.slots_of(w.layer(X6_STAGE["insf"], 16, act, C_BIAS8 + 9 * 256), False)
+    s, _ = WaveX6W.slots_of(w.layer(X6_STAGE["insh"], 8, e, C_BIAS4 + 128), True)
+    acc3 = w.layer(X6_STAGE["inso"], T16, s, C_BIASO)
+    ins = acc3.reshape(2, T16 * 16, 16)[:, : ins_num + 1]
+    out = np.concatenate([rgb, sigma[:, None], ins], 1)            # [p][channel][n]
+    return np.concatenate([out[0].T, out[1].T], 0)                 # [32 points][channels]
+
+
+@pytest.mark.parametrize("ins_num,seed", [(13, 0), (40, 5), (93, 3)])
+def test_x6w_blob_consumed_in_kernel_order_equals_the_field_to_fp32_rounding(ins_num, seed):
+    lib = dm_nerf_amd.load_library()
+    n = lib.dmn_field_pack_index_x6_len(ins_num)               # same size as the x6 blob: same bytes, other order
+    idx = np.empty(n, dtype=np.int32)
+    assert lib.dmn_field_pack_index_x6w(ins_num, idx.ctypes.data) == 0
+    params = oracle.make_params(ins_num, seed)
+    flat = np.concatenate([params[k].numpy().reshape(-1) for k, _ in oracle.param_specs(ins_num)])
+    x, v = cases.field_rows()
+    emb = torch.cat([oracle.encode(torch.from_numpy(x[:32]), 10), oracle.encode(torch.from_numpy(v[:32]), 4)], -1)
+    with torch.no_grad():
+        want32 = oracle.field(params, emb).numpy()
+        want64 = oracle.field({k: p.double() for k, p in params.items()}, emb.double()).numpy()
+    got = simulate_x6w(idx, flat, emb.numpy(), ins_num)
+    assert got.shape == want64.shape
+    err_w, err_ref = rel_err(got, want64), rel_err(want32, want64)
+    assert err_w < 2e-6 and err_w < 2.0 * err_ref + 1e-7, (err_w, err_ref)
+    # the same multiset of parameters as the x6 blob: every weight three times (hi, mid, lo chunk), biases / heads once
+    idx6 = np.empty(n, dtype=np.int32)
+    assert lib.dmn_field_pack_index_x6(ins_num, idx6.ctypes.data) == 0
+    np.testing.assert_array_equal(np.bincount(idx[idx >= 0], minlength=flat.size), np.bincount(idx6[idx6 >= 0], minlength=flat.size))
+
+
 def test_six_product_dot_products_are_as_accurate_as_an_fp32_fma_chain():
     """A 256-term dot product (ReLU-like activations, weights of a 256-wide layer) against its exact value: the six-product
     arithmetic with fp32 accumulation per 16-term block (what a bf16 MFMA does) is no further away than the k-ordered

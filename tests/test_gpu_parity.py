@@ -1302,8 +1302,10 @@ def test_graph_captured_training_step_equals_the_eager_steps():
     # moves single depths -- observed 8e-5 on the emptiness term, 1e-5 on the others)
     for k in last:
         assert abs(float(terms[k]) - float(last[k])) < 1e-3 * max(1.0, abs(float(last[k]))), (k, float(terms[k]), float(last[k]))
+    # Adam's update is m / (sqrt(v) + eps): for an entry whose gradient is within rounding of zero, rounding decides the
+    # update's size -- weights are compared against what four steps can move them at all (4 x lrate = 2e-3; observed 1.5e-5)
     for (k, a), b in zip(eager[3].named_parameters(), graphed[3].parameters()):
-        assert float((a - b).abs().max()) < 2e-4 * float(a.abs().max()) + 1e-7, k
+        assert float((a - b).abs().max()) < 0.05 * 4 * lrate, k
     # the replay reads its inputs from the static buffers: new targets change the colour loss
     before = float(step()["rgb_fine"])
     step.target.copy_(1.0 - step.target)
@@ -1641,6 +1643,29 @@ def test_manipulator_two_pass_rerender_matches_the_reference(golden):
     b = dm.manipulator(pos, view, coarse, fine, rays, f_tar, margs)
     for x, y in zip(a, b):
         np.testing.assert_array_equal(H(x), H(y))
+
+
+@pytest.mark.parametrize("precision", ["bf16x6", "bf16x6_32", "fp32"])
+def test_render_call_is_bit_identical_from_launch_to_launch(precision):
+    """Four dm_nerf calls on the same 150 rays with other kernels (another arithmetic, the compositing and resampling
+    kernels) running in between: every output bit for bit the same.  Guards against reads of memory a kernel does not own --
+    the 16x16x32 kernel once read encoding rows of the neighbouring wave into zero-weight k-slots, where NaN bit patterns
+    left in LDS by whatever ran before survived as sign-dependent zeros: a few rgb values per launch, on some devices."""
+    n = 150
+    o, d, _, _ = cases.path_rays(n, seed=41)
+    pos, view, coarse, fine, args = nets(13, 0, 1)
+    args.precision = precision
+    rays = G(np.stack([o, d], 0))
+    z = dm.z_val_sample(n, cases.NEAR, cases.FAR, cases.N_SAMPLES)
+    other = SimpleNamespace(**{**vars(args), "precision": "fp16x3"})
+    with torch.no_grad():
+        first = dm.dm_nerf(rays, pos, view, coarse, fine, z, args)
+        for _ in range(3):
+            dm.dm_nerf(rays[:, :64], pos, view, coarse, fine, z[:64], other)
+            again = dm.dm_nerf(rays, pos, view, coarse, fine, z, args)
+            for k in first:
+                np.testing.assert_array_equal(H(again[k]), H(first[k]), err_msg=k)
+    assert all(np.isfinite(H(v)).all() for v in first.values())
 
 
 # ---- the one-call C entry for a chunk ----------------------------------------------------------------------

@@ -146,11 +146,19 @@ __device__ __forceinline__ void layer_w(Ctx6& c, f32x4 (*out)[NT], const float* 
         out[p][t] = mfma_w(ah[ar], bh[p], out[p][t]);
       }
       if (dma) {
+#if DMN_X6W_EARLY_DMA       // experiment: two pieces per group in the first six groups (longer lead before the stage barrier)
+        if (2 * gi < kX6PiecesPerWave) { x6_piece<NTP>(c, 2 * gi); x6_piece<NTP>(c, 2 * gi + 1); }
+        if (gi + 1 == groups) {
+#pragma unroll
+          for (int qq = 2 * (gi + 1); qq < kX6PiecesPerWave; ++qq) x6_piece<NTP>(c, qq);
+        }
+#else
         if (gi < kX6PiecesPerWave) x6_piece<NTP>(c, gi);
         if (gi + 1 == groups) {                 // a short stage still owes the rest of its pieces
 #pragma unroll
           for (int qq = gi + 1; qq < kX6PiecesPerWave; ++qq) x6_piece<NTP>(c, qq);
         }
+#endif
       }
       if (ks + 1 < NK) {                        // the next k-step's operand fragments, spread over the tiles
 #pragma unroll

@@ -281,6 +281,60 @@ __device__ __forceinline__ void store_rows_coalesced_w(const float* stage, float
   if (tid < rest) __builtin_nontemporal_store(stage[4 * nvec + tid], dst + 4 * nvec + tid);
 }
 
+// Encodings of point mc into this wave's exchange column `col` (= xch + point): row ch * kXchRow holds channel ch
+// (0..62 position, 63..89 view direction; networks/dm_nerf.py:17-32 order: x y z, then per band sin xyz, cos xyz).
+// The two lanes of a point (h = 0, 1) share its six coordinates -- h = 0: position x, position y, direction z; h = 1:
+// position z, direction x, direction y -- and each writes BOTH the sin and the cos rows of its three: one fp64 sincos
+// and the double-angle chain (trig.h) per coordinate, i.e. half of what the shared prologue (point_encodings: every lane
+// all six, keeping sin or cos) spends, with the same doubles rounded to the same floats.
+__device__ __forceinline__ void encodings_to_exchange(const FieldArgs& a, long mc, int h, float* col) {
+  if (a.emb != nullptr) {                       // embedded mode: copy the row (45 channels per lane)
+    const float* row = a.emb + mc * (kPosCh + kDirCh) + 45 * h;
+#pragma unroll
+    for (int j = 0; j < 45; ++j) col[(45 * h + j) * kXchRow] = row[j];
+    return;
+  }
+  const long n = mc / a.S;
+  const int s = (int)(mc - n * a.S);
+  const float ox = a.rays_o[3 * n + 0], oy = a.rays_o[3 * n + 1], oz = a.rays_o[3 * n + 2];
+  const float dx = a.rays_d[3 * n + 0], dy = a.rays_d[3 * n + 1], dz = a.rays_d[3 * n + 2];
+  const float zv = a.z[n * a.z_stride + s];
+  // pts = rays_o + rays_d * z, viewdirs = rays_d / ||rays_d||: separately rounded, as torch (field_common.h point_encodings)
+  const float px = __fadd_rn(ox, __fmul_rn(dx, zv));
+  const float py = __fadd_rn(oy, __fmul_rn(dy, zv));
+  const float pz = __fadd_rn(oz, __fmul_rn(dz, zv));
+  const float nrm = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+  const float vx = __fdiv_rn(dx, nrm), vy = __fdiv_rn(dy, nrm), vz = __fdiv_rn(dz, nrm);
+  // chain A: position x | z (10 bands); chain B: position y (10 bands) | direction x (4); chain C: direction z | y (4)
+  const float ca = h ? pz : px, cb = h ? vx : py, cc = h ? vy : vz;
+  float* const ra = col + (h ? 2 : 0) * kXchRow;                 // row of the identity channel of each chain
+  float* const rb = col + (h ? kPosCh + 0 : 1) * kXchRow;
+  float* const rc = col + (kPosCh + (h ? 1 : 2)) * kXchRow;
+  ra[0] = ca; rb[0] = cb; rc[0] = cc;
+  double sa, cas, sb, cbs, sc, ccs;
+  sincos_f64(ca, sa, cas);
+  sincos_f64(cb, sb, cbs);
+  sincos_f64(cc, sc, ccs);
+#pragma unroll
+  for (int f = 0; f < kPosFreqs; ++f) {                           // sin row of band f: +3 + 6 f, cos row: +6 + 6 f
+    ra[(3 + 6 * f) * kXchRow] = (float)sa;
+    ra[(6 + 6 * f) * kXchRow] = (float)cas;
+    if (f < kDirFreqs || h == 0) {                                // chain B is a direction (4 bands) in half 1
+      rb[(3 + 6 * f) * kXchRow] = (float)sb;
+      rb[(6 + 6 * f) * kXchRow] = (float)cbs;
+    }
+    if (f < kDirFreqs) {
+      rc[(3 + 6 * f) * kXchRow] = (float)sc;
+      rc[(6 + 6 * f) * kXchRow] = (float)ccs;
+    }
+    if (f + 1 < kPosFreqs) {
+      double_angle(sa, cas);
+      double_angle(sb, cbs);
+      if (f + 1 < kDirFreqs) double_angle(sc, ccs);
+    }
+  }
+}
+
 constexpr int kXchWave = (kPosCh + kDirCh) * kXchRow;  // 2,970 floats per wave
 constexpr int kXchBytes = 4 * kXchWave * 4;            // 47,520 B behind the stage slots and the const section
 static_assert(kX6LdsBytes + kXchBytes <= 160 * 1024, "LDS budget of one CU");
@@ -300,29 +354,15 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6w_kernel(const FieldArgs a
     glds16(blob + k * 1024 + lane * 16, lds + kX6Slots * kX6StageBytes + k * 1024);
   x6_load_stage(c, 0);
 
-  // ---- encodings: computed as everywhere else (lane = point + 32 * half: half 0 the sin terms, half 1 the cos terms of
-  //      one point), then left in LDS for the lanes that need them as k-slots: lane (n, q) of point tile p takes channels
-  //      32 e + 8 q + j of point 16 p + n, where the layers consume them (SrcXch: 80 reads per pass; held in registers
-  //      they cost 48 for most of the kernel).  Rows of 33 floats keep the 32 points of a channel on 32 banks.
+  // ---- encodings: computed by the two lanes of a point (lane = point + 32 * half: three coordinates each,
+  //      encodings_to_exchange) and left in LDS for the lanes that need them as k-slots: lane (n, q) of point tile p
+  //      takes channels 32 e + 8 q + j of point 16 p + n, where the layers consume them (SrcXch: 80 reads per pass; held
+  //      in registers they cost 48 for most of the kernel).  Rows of 33 floats keep the 32 points of a channel on 32 banks.
   float* const xch = reinterpret_cast<float*>(lds + kX6LdsBytes) + wave_s * kXchWave;
   {
     const int pt = lane & 31, h = lane >> 5;
     const long m = ((long)blockIdx.x * 4 + wave_s) * 32 + pt;
-    const long mc = m < a.M ? m : a.M - 1;
-    float pe32[32], qe16[16];
-    point_encodings(a, mc, h, pe32, qe16);
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-      const int c0 = pos_slot(j, 0), c1 = pos_slot(j, 1);
-      const int ch = h ? c1 : c0;
-      if (ch >= 0) xch[(ch >= 0 ? ch : 0) * kXchRow + pt] = pe32[j];
-    }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int c0 = dir_slot(j, 0), c1 = dir_slot(j, 1);
-      const int ch = h ? c1 : c0;
-      if (ch >= 0) xch[(kPosCh + (ch >= 0 ? ch : 0)) * kXchRow + pt] = qe16[j];
-    }
+    encodings_to_exchange(a, m < a.M ? m : a.M - 1, h, xch + pt);
     __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): written before this wave's first read (same wave: in order anyway)
   }
   const float* const xch_lane = xch + 8 * q * kXchRow + n;

@@ -553,75 +553,171 @@ __global__ __launch_bounds__(256, 1) void field_wgrad_ring_kernel(const WgArgs a
     issue(2);
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // half 0
     __syncthreads();
+    if constexpr (X6) {
+      // Six products and three-way conversions: a whole fragment's conversion (52 vector instructions) no longer fits into
+      // the shadow of the product it follows (6 MFMAs hide ~30), and in that arrangement the kernel ran at half its MFMA
+      // rate (6.6 ms per step for the nine big GEMMs).  Here every product carries HALF a conversion (4 of a fragment's 8
+      // values: 22 vector instructions + one 16-byte LDS read, fetched one product ahead), and the order of the products
+      // gives every fragment two products of lead: carried into a half are A0, A1, B0, B1 (converted under the second
+      // half of the half before), products (0,0) (1,0) (0,1) (1,1) convert A2, A3, products (2,0) (3,0) (2,1) (3,1)
+      // convert B2, B3, and the last eight convert the next half's A0, A1, B0, B1 behind the ring hand-over.
+      F fa[OTW], fb[4], nfa[2];
+      auto fetch_half = [&](const char* row, int half) { return *reinterpret_cast<const f32x4*>(row + (half ? off1 : off0)); };
+      auto half_sum = [](const f32x4& v) { return (v.x + v.y) + (v.z + v.w); };
+      auto split_half = [&](const f32x4& v, int half, F& f) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        auto back = [](const bf16x4& q) {
+          const u32x2 w = __builtin_bit_cast(u32x2, q);
+          return f32x4{__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
+                       __builtin_bit_cast(float, w.y << 16), __builtin_bit_cast(float, w.y & 0xffff0000u)};
+        };
+        const bf16x4 hh = __builtin_convertvector(v, bf16x4);
+        const f32x4 r1 = v - back(hh);
+        const bf16x4 mm = __builtin_convertvector(r1, bf16x4);
+        const bf16x4 ll = __builtin_convertvector(r1 - back(mm), bf16x4);
+        if (half == 0) {
+          f.h = __builtin_shufflevector(hh, hh, 0, 1, 2, 3, 0, 1, 2, 3);
+          f.m = __builtin_shufflevector(mm, mm, 0, 1, 2, 3, 0, 1, 2, 3);
+          f.l = __builtin_shufflevector(ll, ll, 0, 1, 2, 3, 0, 1, 2, 3);
+        } else {
+          const bf16x8 eh = __builtin_shufflevector(hh, hh, 0, 1, 2, 3, 0, 1, 2, 3);
+          const bf16x8 em = __builtin_shufflevector(mm, mm, 0, 1, 2, 3, 0, 1, 2, 3);
+          const bf16x8 el = __builtin_shufflevector(ll, ll, 0, 1, 2, 3, 0, 1, 2, 3);
+          f.h = __builtin_shufflevector(f.h, eh, 0, 1, 2, 3, 8, 9, 10, 11);
+          f.m = __builtin_shufflevector(f.m, em, 0, 1, 2, 3, 8, 9, 10, 11);
+          f.l = __builtin_shufflevector(f.l, el, 0, 1, 2, 3, 8, 9, 10, 11);
+        }
+      };
+      const int arow = (wr * OTW * 32 + l) * 64, brow = (256 + wc * KTW * 32 + l) * 64;
+      {                                                      // half 0: A0, A1, B0, B1 up front
+        const char* pa = lds + arow;
+        const char* pb = lds + brow;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const f32x4 va = fetch_half(pa + i * 32 * 64, hf), vb = fetch_half(pb + i * 32 * 64, hf);
+            split_half(va, hf, fa[i]);
+            split_half(vb, hf, fb[i]);
+            bsum[i] += half_sum(va);
+          }
+      }
+      for (long h = 0; h < H; ++h) {
+        const char* pa = lds + (int)(h & (RING - 1)) * HB + arow;
+        const char* pb = lds + (int)(h & (RING - 1)) * HB + brow;
+        const char* na = lds + (int)((h + 1) & (RING - 1)) * HB + arow;
+        const char* nb = lds + (int)((h + 1) & (RING - 1)) * HB + brow;
+        const bool more = h + 1 < H;
+        f32x4 r = fetch_half(pa + 2 * 32 * 64, 0), rn;
+        // one product: the next conversion's raw values are fetched above the fence, the product's six MFMAs and the
+        // conversion of the values fetched one product earlier share the region below it
+#define DMN_STEP(I, J, FETCH, CONVERT) \
+        rn = FETCH;                      \
+        DMN_FENCE();                     \
+        triple(I, J, fa[I], fb[J]);      \
+        CONVERT;                         \
+        r = rn;
+        DMN_STEP(0, 0, fetch_half(pa + 2 * 32 * 64, 1), (split_half(r, 0, fa[2]), bsum[2] += half_sum(r)))
+        DMN_STEP(1, 0, fetch_half(pa + 3 * 32 * 64, 0), (split_half(r, 1, fa[2]), bsum[2] += half_sum(r)))
+        DMN_STEP(0, 1, fetch_half(pa + 3 * 32 * 64, 1), (split_half(r, 0, fa[3]), bsum[3] += half_sum(r)))
+        DMN_STEP(1, 1, fetch_half(pb + 2 * 32 * 64, 0), (split_half(r, 1, fa[3]), bsum[3] += half_sum(r)))
+        DMN_STEP(2, 0, fetch_half(pb + 2 * 32 * 64, 1), split_half(r, 0, fb[2]))
+        DMN_STEP(3, 0, fetch_half(pb + 3 * 32 * 64, 0), split_half(r, 1, fb[2]))
+        DMN_STEP(2, 1, fetch_half(pb + 3 * 32 * 64, 1), split_half(r, 0, fb[3]))
+        DMN_FENCE();
+        triple(3, 1, fa[3], fb[1]);
+        split_half(r, 1, fb[3]);
+        DMN_FENCE();
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // this wave's pieces of half h+1 (half h+2 stays in flight)
+        __syncthreads();                                     // ... everybody's; and everybody is past half h-1
+        issue(h + 3);                                        // into the slot of half h-1
+        r = fetch_half(na, 0);
+        DMN_STEP(0, 2, fetch_half(na, 1), (split_half(r, 0, nfa[0]), bsum[0] += more ? half_sum(r) : 0.f))
+        DMN_STEP(1, 2, fetch_half(na + 32 * 64, 0), (split_half(r, 1, nfa[0]), bsum[0] += more ? half_sum(r) : 0.f))
+        DMN_STEP(2, 2, fetch_half(na + 32 * 64, 1), (split_half(r, 0, nfa[1]), bsum[1] += more ? half_sum(r) : 0.f))
+        DMN_STEP(3, 2, fetch_half(nb, 0), (split_half(r, 1, nfa[1]), bsum[1] += more ? half_sum(r) : 0.f))
+        DMN_STEP(0, 3, fetch_half(nb, 1), split_half(r, 0, fb[0]))          // B0, B1 of this half are done
+        DMN_STEP(1, 3, fetch_half(nb + 32 * 64, 0), split_half(r, 1, fb[0]))
+        DMN_STEP(2, 3, fetch_half(nb + 32 * 64, 1), split_half(r, 0, fb[1]))
+        DMN_FENCE();
+        triple(3, 3, fa[3], fb[3]);
+        split_half(r, 1, fb[1]);
+        DMN_FENCE();
+#undef DMN_STEP
+        fa[0] = nfa[0];
+        fa[1] = nfa[1];
+      }
+    } else {
     // A0 / B0 of the half about to be multiplied are converted at the end of the half before (here: up front)
-    F fa[OTW], fb[2], nfa, nfb;
-    {
-      const Raw ra = fetch_row(lds + (wr * OTW * 32 + l) * 64), rb = fetch_row(lds + (256 + wc * KTW * 32 + l) * 64);
-      split(ra, nfa);
-      split(rb, nfb);
-      bsum[0] += row_sum(ra);
-    }
-    for (long h = 0; h < H; ++h) {
-      const char* pa = lds + (int)(h & (RING - 1)) * HB + (wr * OTW * 32 + l) * 64;
-      const char* pb = lds + (int)(h & (RING - 1)) * HB + (256 + wc * KTW * 32 + l) * 64;
-      const char* na = lds + (int)((h + 1) & (RING - 1)) * HB + (wr * OTW * 32 + l) * 64;
-      const char* nb = lds + (int)((h + 1) & (RING - 1)) * HB + (256 + wc * KTW * 32 + l) * 64;
-      fa[0] = nfa; fb[0] = nfb;
-      // the schedule: every MFMA triple carries the conversion of a fragment needed later, raw rows are read one step
-      // before they are converted; the ring hand-over (wait, barrier, re-issue) sits in the middle of the half
-      Raw r = fetch_row(pa + 1 * 32 * 64);
-      DMN_FENCE();
-      triple(0, 0, fa[0], fb[0]);
-      split(r, fa[1]); bsum[1] += row_sum(r);
-      r = fetch_row(pa + 2 * 32 * 64);
-      DMN_FENCE();
-      triple(1, 0, fa[1], fb[0]);
-      split(r, fa[2]); bsum[2] += row_sum(r);
-      r = fetch_row(pa + 3 * 32 * 64);
-      DMN_FENCE();
-      triple(2, 0, fa[2], fb[0]);
-      split(r, fa[3]); bsum[3] += row_sum(r);
-      r = fetch_row(pb + 1 * 32 * 64);
-      DMN_FENCE();
-      triple(3, 0, fa[3], fb[0]);
-      split(r, fb[1]);
-      r = fetch_row(pb + 2 * 32 * 64);
-      DMN_FENCE();
-      triple(0, 1, fa[0], fb[1]);
-      split(r, fb[0]);                               // B2 (B0 is done)
-      r = fetch_row(pb + 3 * 32 * 64);
-      DMN_FENCE();
-      triple(1, 1, fa[1], fb[1]);
-      DMN_FENCE();
-      triple(2, 1, fa[2], fb[1]);
-      DMN_FENCE();
-      triple(3, 1, fa[3], fb[1]);
-      DMN_FENCE();
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // this wave's pieces of half h+1 (half h+2 stays in flight)
-      __syncthreads();                                     // ... everybody's; and everybody is past half h-1
-      issue(h + 3);                                        // into the slot of half h-1
-      DMN_FENCE();
-      triple(0, 2, fa[0], fb[0]);
-      split(r, fb[1]);                               // B3 (B1 is done)
-      Raw rn = fetch_row(na);
-      DMN_FENCE();
-      triple(1, 2, fa[1], fb[0]);
-      split(rn, nfa); bsum[0] += h + 1 < H ? row_sum(rn) : 0.f;
-      rn = fetch_row(nb);
-      DMN_FENCE();
-      triple(2, 2, fa[2], fb[0]);
-      split(rn, nfb);
-      DMN_FENCE();
-      triple(3, 2, fa[3], fb[0]);
-      DMN_FENCE();
-      triple(0, 3, fa[0], fb[1]);
-      DMN_FENCE();
-      triple(1, 3, fa[1], fb[1]);
-      DMN_FENCE();
-      triple(2, 3, fa[2], fb[1]);
-      DMN_FENCE();
-      triple(3, 3, fa[3], fb[1]);
-      DMN_FENCE();
+      F fa[OTW], fb[2], nfa, nfb;
+      {
+        const Raw ra = fetch_row(lds + (wr * OTW * 32 + l) * 64), rb = fetch_row(lds + (256 + wc * KTW * 32 + l) * 64);
+        split(ra, nfa);
+        split(rb, nfb);
+        bsum[0] += row_sum(ra);
+      }
+      for (long h = 0; h < H; ++h) {
+        const char* pa = lds + (int)(h & (RING - 1)) * HB + (wr * OTW * 32 + l) * 64;
+        const char* pb = lds + (int)(h & (RING - 1)) * HB + (256 + wc * KTW * 32 + l) * 64;
+        const char* na = lds + (int)((h + 1) & (RING - 1)) * HB + (wr * OTW * 32 + l) * 64;
+        const char* nb = lds + (int)((h + 1) & (RING - 1)) * HB + (256 + wc * KTW * 32 + l) * 64;
+        fa[0] = nfa; fb[0] = nfb;
+        // the schedule: every MFMA triple carries the conversion of a fragment needed later, raw rows are read one step
+        // before they are converted; the ring hand-over (wait, barrier, re-issue) sits in the middle of the half
+        Raw r = fetch_row(pa + 1 * 32 * 64);
+        DMN_FENCE();
+        triple(0, 0, fa[0], fb[0]);
+        split(r, fa[1]); bsum[1] += row_sum(r);
+        r = fetch_row(pa + 2 * 32 * 64);
+        DMN_FENCE();
+        triple(1, 0, fa[1], fb[0]);
+        split(r, fa[2]); bsum[2] += row_sum(r);
+        r = fetch_row(pa + 3 * 32 * 64);
+        DMN_FENCE();
+        triple(2, 0, fa[2], fb[0]);
+        split(r, fa[3]); bsum[3] += row_sum(r);
+        r = fetch_row(pb + 1 * 32 * 64);
+        DMN_FENCE();
+        triple(3, 0, fa[3], fb[0]);
+        split(r, fb[1]);
+        r = fetch_row(pb + 2 * 32 * 64);
+        DMN_FENCE();
+        triple(0, 1, fa[0], fb[1]);
+        split(r, fb[0]);                               // B2 (B0 is done)
+        r = fetch_row(pb + 3 * 32 * 64);
+        DMN_FENCE();
+        triple(1, 1, fa[1], fb[1]);
+        DMN_FENCE();
+        triple(2, 1, fa[2], fb[1]);
+        DMN_FENCE();
+        triple(3, 1, fa[3], fb[1]);
+        DMN_FENCE();
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // this wave's pieces of half h+1 (half h+2 stays in flight)
+        __syncthreads();                                     // ... everybody's; and everybody is past half h-1
+        issue(h + 3);                                        // into the slot of half h-1
+        DMN_FENCE();
+        triple(0, 2, fa[0], fb[0]);
+        split(r, fb[1]);                               // B3 (B1 is done)
+        Raw rn = fetch_row(na);
+        DMN_FENCE();
+        triple(1, 2, fa[1], fb[0]);
+        split(rn, nfa); bsum[0] += h + 1 < H ? row_sum(rn) : 0.f;
+        rn = fetch_row(nb);
+        DMN_FENCE();
+        triple(2, 2, fa[2], fb[0]);
+        split(rn, nfb);
+        DMN_FENCE();
+        triple(3, 2, fa[3], fb[0]);
+        DMN_FENCE();
+        triple(0, 3, fa[0], fb[1]);
+        DMN_FENCE();
+        triple(1, 3, fa[1], fb[1]);
+        DMN_FENCE();
+        triple(2, 3, fa[2], fb[1]);
+        DMN_FENCE();
+        triple(3, 3, fa[3], fb[1]);
+        DMN_FENCE();
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the ring's last (unused) fetches must land before the LDS goes
   }

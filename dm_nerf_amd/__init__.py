@@ -17,7 +17,7 @@ from .manipulator import exchanger, manipulator, manipulator_nerf, manipulator_r
 from .ops import DEFAULT_PRECISION, PRECISIONS
 from .penalizer import emptiness_penalizer, ins_penalizer
 from .render import dm_nerf, render_train
-from .tester import render_image, render_test
+from .tester import GraphedImage, render_image, render_test
 from . import autograd, parallel, synthetic, trainer
 
 # nerf-pytorch names used by BASELINE.json's north_star
@@ -28,6 +28,6 @@ render_path = render_test
 __all__ = [
     "HipLibraryError", "LIB_PATH", "load_library", "create_nerf", "default_args", "DM_NeRF", "Embedder",
     "get_embedder", "emptiness_penalizer", "ins_penalizer", "ins_criterion", "ins_criterion_many", "img2mse", "mse2psnr", "get_rays_k", "get_select_full", "get_select_crop", "sample_pdf", "z_val_sample", "manipulator_nerf", "manipulator_render", "exchanger", "manipulator",
-    "dm_nerf", "render_train", "render_image", "render_test", "render", "raw2outputs", "render_path", "parallel",
+    "dm_nerf", "render_train", "render_image", "GraphedImage", "render_test", "render", "raw2outputs", "render_path", "parallel",
     "trainer", "DEFAULT_PRECISION", "PRECISIONS",
 ]

@@ -15,35 +15,24 @@ from .helpers import _unit_linspace, get_rays_k, z_val_sample
 from .render import dm_nerf
 
 
-def render_image(position_embedder, view_embedder, model_coarse, model_fine, c2w, hwk, args,
-                 chunk: Optional[int] = None, crop_mask=None, ray_range: Optional[Tuple[int, int]] = None,
-                 image_only: bool = False):
-    """Render one pose.  ``chunk`` defaults to ``args.N_test`` (tester.py:62); the reference's
-    O(chunks^2) ``torch.cat`` growth (tester.py:72-76) is replaced by writes into preallocated
-    images.  ``ray_range=(a, b)`` renders only flat rays ``[a, b)`` (multi-GPU sharding of one
-    image) and returns flat ``[b-a, .]`` tensors.  With rows wider than 32 channels the chunks of every arithmetic but the
-    exact-fp32 one run through the fused field + compositing kernels (``ops.render_fused``).  ``image_only`` (the same
-    arithmetics): the coarse network evaluates
-    its density only -- the colour / instance heads of the coarse pass feed nothing this loop returns
-    (tester.py:70-76 keeps ``rgb_fine`` and ``ins_fine``); the returned images are bit-identical."""
-    H, W, K = hwk
-    chunk = int(chunk or args.N_test)
-    # fp32-grade arithmetic unless the caller says otherwise (ops.DEFAULT_PRECISION = "bf16x6": all 24 bits of every fp32
-    # operand enter the products; same default as dm_nerf()).  args.precision = "fp32" selects the exact-fp32 MFMA kernel,
-    # "fp16x3" | "bf16x3" the two-way split kernels (three 16-bit MFMAs per product: 1e-6 / 7e-6 on raw against the
-    # reference, 1.7x the default's rays/s) -- narrower arithmetic is never chosen silently.
+def _resolved(args, image_only: bool):
+    """``args`` with ``precision`` filled in (``ops.DEFAULT_PRECISION`` unless the caller said otherwise) and the coarse
+    pass's heads switched off for ``image_only``."""
     precision = getattr(args, "precision", None) or ops.DEFAULT_PRECISION
     if image_only and precision == "fp32":
         raise ValueError("image_only (density-only coarse pass) is a mode of the bf16 / fp16 matrix-pipe kernels: set "
                          "args.precision to 'bf16x6', 'fp16x3' or 'bf16x3'")
     if getattr(args, "precision", None) != precision or image_only:
         args = SimpleNamespace(**{**vars(args), "precision": precision, "coarse_heads": not image_only})
-    if precision == "fp16x3":
-        ops.take_status(torch.device("cuda", torch.cuda.current_device()))      # clear stale flags
-    rays_o, rays_d = get_rays_k(H, W, K, c2w)                                   # tester.py:58
-    rays_o = rays_o.reshape(-1, 3)
-    rays_d = rays_d.reshape(-1, 3)
-    lo, hi = (0, H * W) if ray_range is None else ray_range
+    return args
+
+
+def _render_rays(position_embedder, view_embedder, model_coarse, model_fine, rays_o, rays_d, args, chunk: int,
+                 ray_range: Tuple[int, int], image_only: bool):
+    """The chunk loop (tester.py:62-76) over flat rays ``[lo, hi)`` of ``rays_o`` / ``rays_d`` [H*W, 3]: rgb [hi-lo, 3] and
+    instance map [hi-lo, ins_num], written chunk by chunk into preallocated buffers.  ``args.precision`` is resolved."""
+    precision = args.precision
+    lo, hi = ray_range
     n_total = hi - lo
     rgb = torch.empty(n_total, 3, dtype=torch.float32, device=rays_o.device)
     ins = torch.empty(n_total, model_fine.ins_num, dtype=torch.float32, device=rays_o.device)
@@ -74,6 +63,33 @@ def render_image(position_embedder, view_embedder, model_coarse, model_fine, c2w
                 out = dm_nerf(batch, position_embedder, view_embedder, model_coarse, model_fine, z, args)
             rgb[start - lo:start - lo + n] = out["rgb_fine"]
             ins[start - lo:start - lo + n] = out["ins_fine"]
+    return rgb, ins
+
+
+def render_image(position_embedder, view_embedder, model_coarse, model_fine, c2w, hwk, args,
+                 chunk: Optional[int] = None, crop_mask=None, ray_range: Optional[Tuple[int, int]] = None,
+                 image_only: bool = False):
+    """Render one pose.  ``chunk`` defaults to ``args.N_test`` (tester.py:62); the reference's
+    O(chunks^2) ``torch.cat`` growth (tester.py:72-76) is replaced by writes into preallocated
+    images.  ``ray_range=(a, b)`` renders only flat rays ``[a, b)`` (multi-GPU sharding of one
+    image) and returns flat ``[b-a, .]`` tensors.  With rows wider than 32 channels the chunks of every arithmetic but the
+    exact-fp32 one run through the fused field + compositing kernels (``ops.render_fused``).  ``image_only`` (the same
+    arithmetics): the coarse network evaluates
+    its density only -- the colour / instance heads of the coarse pass feed nothing this loop returns
+    (tester.py:70-76 keeps ``rgb_fine`` and ``ins_fine``); the returned images are bit-identical."""
+    H, W, K = hwk
+    chunk = int(chunk or args.N_test)
+    # fp32-grade arithmetic unless the caller says otherwise (ops.DEFAULT_PRECISION = "bf16x6": all 24 bits of every fp32
+    # operand enter the products; same default as dm_nerf()).  args.precision = "fp32" selects the exact-fp32 MFMA kernel,
+    # "fp16x3" | "bf16x3" the two-way split kernels (three 16-bit MFMAs per product: 1e-6 / 7e-6 on raw against the
+    # reference, 1.7x the default's rays/s) -- narrower arithmetic is never chosen silently.
+    args = _resolved(args, image_only)
+    precision = args.precision
+    if precision == "fp16x3":
+        ops.take_status(torch.device("cuda", torch.cuda.current_device()))      # clear stale flags
+    rays_o, rays_d = get_rays_k(H, W, K, c2w)                                   # tester.py:58
+    rgb, ins = _render_rays(position_embedder, view_embedder, model_coarse, model_fine, rays_o.reshape(-1, 3),
+                            rays_d.reshape(-1, 3), args, chunk, (0, H * W) if ray_range is None else ray_range, image_only)
     if precision == "fp16x3" and ops.take_status(rgb.device) & ops.STATUS_FP16_RANGE:
         # an activation left the fp16 range somewhere in this image: redo it with exact fp32 products
         warnings.warn("dm_nerf_amd: fp16x3 range exceeded, re-rendering this image with precision='fp32'")
@@ -88,6 +104,61 @@ def render_image(position_embedder, view_embedder, model_coarse, model_fine, c2w
         return (rgb.reshape(args.crop_height, args.crop_width, 3),
                 ins.reshape(args.crop_height, args.crop_width, ins.shape[-1]))
     return rgb.reshape(H, W, 3), ins.reshape(H, W, ins.shape[-1])
+
+
+class GraphedImage:
+    """The chunk loop of one image (networks/tester.py:62-76) captured as ONE hipGraph: every launch of every chunk -- at
+    the reference's ``N_test = 4096`` that is 157 ``dm_nerf`` calls, ~1 900 kernels per 800x800 image -- replays with a single
+    host call per image.  The device is not idle in the eager loop on an unloaded host (``bench.py``: ``chunk_4096`` runs at
+    0.995 - 1.02 of the 65536-ray rate), so this buys nothing there; it is the form for a host that cannot keep ~2 000
+    launches per image ahead of the device.
+
+        renderer = GraphedImage(pos, view, coarse, fine, [H, W, K], args, chunk=4096)
+        rgb, ins = renderer(c2w)          # [H, W, 3], [H, W, ins_num]: views of static buffers, overwritten by the next call
+
+    Rays are generated eagerly per pose (the camera is a by-value kernel argument) into static buffers the graph reads.
+    Inference only: the graph holds the weight blobs of the moment of capture -- call ``refresh()`` after the weights
+    change.  Same kernels on the same values as ``render_image``: bit-identical images."""
+
+    def __init__(self, position_embedder, view_embedder, model_coarse, model_fine, hwk, args, chunk: Optional[int] = None,
+                 image_only: bool = False):
+        self._nerf = (position_embedder, view_embedder, model_coarse, model_fine)
+        self.hwk, self.args, self.chunk, self.image_only = hwk, _resolved(args, image_only), int(chunk or args.N_test), image_only
+        if self.args.precision == "fp16x3":
+            raise ValueError("GraphedImage: 'fp16x3' needs its range flag read back per image (render_image does); use "
+                             "'bf16x6', 'fp32' or 'bf16x3'")
+        if float(self.args.perturb) != 0.0:
+            raise ValueError("GraphedImage renders the deterministic path (perturb = 0)")
+        self.graph = None
+        self.refresh()
+
+    def refresh(self) -> None:
+        H, W, K = self.hwk
+        pos, view, coarse, fine = self._nerf
+        dev = next(fine.parameters()).device
+        eye = torch.eye(4)[:3].numpy()
+        render_image(pos, view, coarse, fine, eye, self.hwk, self.args, chunk=self.chunk, image_only=self.image_only,
+                     ray_range=(0, min(H * W, 2 * self.chunk)))              # warm-up: blobs, tables, kernels loaded
+        self.rays_o = torch.empty(H * W, 3, dtype=torch.float32, device=dev)
+        self.rays_d = torch.empty(H * W, 3, dtype=torch.float32, device=dev)
+        self.rays_o.zero_(); self.rays_d.fill_(1.0)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            _render_rays(pos, view, coarse, fine, self.rays_o, self.rays_d, self.args, self.chunk, (0, H * W), self.image_only)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.rgb, self.ins = _render_rays(pos, view, coarse, fine, self.rays_o, self.rays_d, self.args, self.chunk,
+                                              (0, H * W), self.image_only)
+
+    def __call__(self, c2w):
+        H, W, K = self.hwk
+        rays_o, rays_d = get_rays_k(H, W, K, c2w)
+        self.rays_o.copy_(rays_o.reshape(-1, 3))
+        self.rays_d.copy_(rays_d.reshape(-1, 3))
+        self.graph.replay()
+        return self.rgb.reshape(H, W, 3), self.ins.reshape(H, W, self.ins.shape[-1])
 
 
 def render_test(position_embedder, view_embedder, model_coarse, model_fine, render_poses, hwk, args, gt_imgs=None,

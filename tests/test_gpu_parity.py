@@ -1645,6 +1645,24 @@ def test_manipulator_two_pass_rerender_matches_the_reference(golden):
         np.testing.assert_array_equal(H(x), H(y))
 
 
+@pytest.mark.parametrize("chunk", [100, 4096])
+def test_graph_captured_image_loop_equals_the_eager_loop(chunk):
+    """tester.GraphedImage: the whole chunk loop of an image as one hipGraph replay -- bit-identical to render_image for
+    several poses from one capture (ragged last chunk; the reference's N_test and a small chunk), static output buffers."""
+    Hh, W = 41, 37
+    pos, view, coarse, fine, args = nets(13, 0, 1)
+    hwk = [Hh, W, cases.study_intrinsics(Hh, W)]
+    renderer = dm.GraphedImage(pos, view, coarse, fine, hwk, args, chunk=chunk)
+    for i in (0, 3, 5):
+        c2w = oracle.study_pose(i)
+        rgb, ins = renderer(c2w)
+        want_rgb, want_ins = dm.render_image(pos, view, coarse, fine, c2w, hwk, args, chunk=chunk)
+        np.testing.assert_array_equal(H(rgb), H(want_rgb))
+        np.testing.assert_array_equal(H(ins), H(want_ins))
+    with pytest.raises(ValueError):
+        dm.GraphedImage(pos, view, coarse, fine, hwk, SimpleNamespace(**{**vars(args), "precision": "fp16x3"}))
+
+
 @pytest.mark.parametrize("precision", ["bf16x6", "bf16x6_32", "fp32"])
 def test_render_call_is_bit_identical_from_launch_to_launch(precision):
     """Four dm_nerf calls on the same 150 rays with other kernels (another arithmetic, the compositing and resampling

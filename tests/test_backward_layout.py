@@ -198,3 +198,28 @@ def test_backward_data_blobs_hold_the_transposed_weights(ins_num):
             c = stream3[ch * X3_CHUNK:(ch + 1) * X3_CHUNK].reshape(64, 8)
             for jj in range(8):
                 np.testing.assert_array_equal(c[:, jj], at + feat_of(8 * ks + jj, HALF) * shape[1] + 32 * t + P)
+
+    # x6 stream (field_bwd_x6.hip): k-steps outer, [hi, mid, lo] chunk triples per (k-step, tile) group, 48-chunk stages;
+    # every weight the chain multiplies by three times, nothing else; group (ks, t) of mlps.3^T, all three planes alike
+    n6 = lib.dmn_field_bwd_pack_index_x6_len(ins_num)
+    stages6 = (1 if T <= 2 else 2) + 4 + 4 + 8 + 7 * 8
+    assert n6 == CONST + stages6 * 48 * X3_CHUNK and lib.dmn_field_bwd_blob_x6_bytes(ins_num) == CONST * 4 + stages6 * 48 * 1024
+    idx6 = np.empty(n6, dtype=np.int32)
+    assert lib.dmn_field_bwd_pack_index_x6(ins_num, idx6.ctypes.data) == 0
+    stream6 = idx6[CONST:]
+    np.testing.assert_array_equal(np.bincount(stream6[stream6 >= 0], minlength=total), 3 * expect)
+    np.testing.assert_array_equal(idx6[:CONST], idx[:CONST])
+    s0 = (1 if T <= 2 else 2) + 4 + 4 + 8 + 8 * (7 - 3)
+    for t, ks in ((0, 0), (5, 9), (7, 15)):
+        for plane in range(3):
+            ch = (s0 + ks // 2) * 48 + ((ks % 2) * 8 + t) * 3 + plane
+            c = stream6[ch * X3_CHUNK:(ch + 1) * X3_CHUNK].reshape(64, 8)
+            for jj in range(8):
+                np.testing.assert_array_equal(c[:, jj], at + feat_of(8 * ks + jj, HALF) * shape[1] + 32 * t + P)
+    # ins_linear^T heads the stream: 4 tiles x 2 T k-steps, 4 k-steps per stage; channels past ins_num are padding
+    at_o, shape_o = off["ins_linear.weight"]
+    c = stream6[0:X3_CHUNK].reshape(64, 8)                                   # k-step 0, tile 0, hi plane
+    for jj in range(8):
+        ch_k = feat_of(jj, HALF)                                             # channel held by k-slot jj of lane-half h
+        want = np.where(ch_k <= ins_num, at_o + ch_k * shape_o[1] + P, -1)
+        np.testing.assert_array_equal(c[:, jj], want)

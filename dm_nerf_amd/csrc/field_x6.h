@@ -44,6 +44,9 @@ typedef P6::frag frag;
 #ifndef DMN_X6_ORDER
 #define DMN_X6_ORDER 0
 #endif
+#ifndef DMN_X6_ABL
+#define DMN_X6_ABL 0
+#endif
 #ifndef DMN_X6_SCALAR_SUB
 #define DMN_X6_SCALAR_SUB 1
 #endif
@@ -88,11 +91,15 @@ __device__ __forceinline__ void x6_load_stage(const Ctx6& c, int g) {
 __device__ __forceinline__ void x6_stage_begin(Ctx6& c) {
   // this wave's LDS-DMA pieces of the stage (inline asm: not in the compiler's count).  Three slots without the
   // read-ahead: all but the 12 youngest vector-memory operations -- the pieces of the stage after this one
-  if (kX6Slots == 3 && !kX6CrossBarrier)
+#if DMN_X6_ABL != 1 && DMN_X6_ABL != 3       // timing-only ablations (results are wrong): 1 no wait for the stage's DMA,
+  if (kX6Slots == 3 && !kX6CrossBarrier)   // 2 no DMA behind the first stages, 3 neither wait nor barrier
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#if DMN_X6_ABL != 3
   __syncthreads();
+#endif
   c.buf = c.lds + x6_slot(c.g) * kX6StageBytes + c.lane * 16;
   ++c.g;
 }
@@ -103,6 +110,9 @@ __device__ __forceinline__ void x6_stage_begin(Ctx6& c) {
 // the piece's own offset is added inside the asm statement (glds16_at).
 template <int Q, bool NT>
 __device__ __forceinline__ void x6_load_piece(const Ctx6& c) {
+#if DMN_X6_ABL == 2
+  return;
+#endif
   const int gt = c.g + kX6Slots - 2;
   const int g = gt < c.G ? gt : c.G - 1;
   const char* src = c.stream + ((unsigned)g * (unsigned)kX6StageBytes + (unsigned)(c.wave_s * kX6PiecesPerWave * 1024));

@@ -16,6 +16,11 @@
 // sets (2 x 128 registers) alternate as input and output, a k-step's operands are read, activated and split one
 // k-step ahead in the MFMA shadow, exactly as in field_x6.h.  The saving (training) forward and the fused kernel stay on
 // the 32x32x16 kernel: their save record and compositing slab are tied to its lane map.
+//
+// Launch: ONE workgroup per CU (163 KB of LDS: a CU holds one) that walks the launch's 128-point tiles round robin
+// (x6w_tiles).  The weight stream wraps from a tile's last stage into stage 0 of the next, the const section is loaded once,
+// and the dispatcher starts 256 workgroups instead of ~100 000: -6.7 % per launch against one tile per workgroup, where
+// every tile paid dispatch + const section + the latency of its first stage with nothing of its CU's to hide behind.
 #include <hip/hip_runtime.h>
 
 #include "../../include/dmnerf_hip.h"
@@ -54,13 +59,17 @@ struct SrcXch {
 };
 // h8 = relu(mlps.7) for its second reader (ins_feature_linear): feature tiles 0 .. kKeepTo-1 activated in vector registers
 // (kept by rgb_feature_linear's operand split, see x6w_network), tiles kKeepTo .. 15 still in their accumulators.
-// The FIRST ten tiles: rgb_feature_linear consumes its input tiles in ascending order, so the tiles that must outlive it in
-// accumulator registers are the ones it releases last -- its own output (128 registers) then meets at most 96 of h8, never
-// all 128.  (Keeping the last tiles in vector registers instead leaves the allocator without a spare tuple for the first
-// k-steps: it moves finished tiles of h8 to vector registers and on to scratch, 116 - 164 B per lane, and that traffic
-// evicts the weight stream from the L2: FETCH_SIZE 5.7 GB per launch against 0.85.)
-constexpr int kKeepTo = 10;
-constexpr int kKeepRegs = 4 * kKeepTo;
+// kKeepTo = 0: all of h8 stays in its accumulators and is activated again where it is read again.  The register file is
+// full to the last tuple either way and the allocator's answer to one more live value is scratch, whose traffic evicts the
+// weight stream from the L2 (FETCH_SIZE 5.7 GB per launch against 0.85 with 164 B of it), so this is measured, not reasoned:
+// as one tile per workgroup the kernel was free of scratch with the FIRST ten tiles kept (rgb_feature_linear consumes its
+// input in ascending order; its 128 output registers then meet at most 96 of h8) and spilled with none; as a loop over tiles
+// (x6w_tiles) it spills 17 / 53 / 81 / 124 registers with 4 / 8 / 10 / 14 tiles kept and none with 0 or 2 (equal in time).
+#ifndef DMN_X6W_KEEP
+#define DMN_X6W_KEEP 0
+#endif
+constexpr int kKeepTo = DMN_X6W_KEEP;
+constexpr int kKeepRegs = kKeepTo ? 4 * kKeepTo : 1;
 struct SrcH8W {
   const f32x4 (*a)[16];
   const float (*keep)[kKeepRegs];
@@ -74,10 +83,10 @@ struct SrcH8W {
 // (ReLU first if RELU) and the NKX k-steps of `ext` (encodings) of the six-term product with the stream's chunk triples.
 //   bias   LDS address of this lane group's bias floats of tile 0 (natural feature order: + 16 t per tile)
 //   KEEP   the activated values of source tiles 0 .. kKeepTo-1 stay behind in keep[p][4 t + r]
-//   LAST   the layer ends the weight stream: no LDS-DMA is issued during its last stage
+//   LAST   the layer ends the weight stream: its last stage issues LDS-DMA (stage 0 again) only if `more` (another tile follows)
 template <int LID, int NT, int NKS, int NKX, bool RELU, bool KEEP, bool LAST, class Src, class Ext>
 __device__ __forceinline__ void layer_w(Ctx6& c, f32x4 (*out)[NT], const float* bias, const Src& src, const Ext& ext,
-                                        float (*keep)[kKeepRegs] = nullptr) {
+                                        float (*keep)[kKeepRegs] = nullptr, bool more = false) {
   constexpr int NK = NKS + NKX;
   constexpr int KPS = x6w_kps(NT);              // k-steps per 16-group stage
   constexpr bool NTP = ((DMN_X6_NTMASK >> LID) & 1) != 0;
@@ -117,7 +126,7 @@ __device__ __forceinline__ void layer_w(Ctx6& c, f32x4 (*out)[NT], const float* 
     constexpr int kLastStage = (NK - 1) / KPS;
     const int stage = ks / KPS;
     const int groups = (stage == kLastStage ? NK - stage * KPS : KPS) * NT;
-    const bool dma = !(LAST && stage == kLastStage);
+    const bool dma = !(LAST && stage == kLastStage) || more;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int gi = (ks % KPS) * NT + t;       // group inside its stage
@@ -187,15 +196,14 @@ __device__ __forceinline__ float sum_groups(float x) {
 // acc3[p][t][r] = instance logit of channel 16 t + 4 q + r.  With sigma_only the network stops behind its density head
 // and returns true (see x6_network).
 template <int T16>
-__device__ __forceinline__ bool x6w_network(Ctx6& c, const float* cst, const float* xch_lane, int q,
-                                            bool sigma_only, float (&sigma)[2], float (&rgb)[2][3], f32x4 (&acc3)[2][T16]) {
+__device__ __forceinline__ bool x6w_network(Ctx6& c, const float* cst, const float* xch_lane, int q, bool sigma_only,
+                                            bool more, float (&sigma)[2], float (&rgb)[2][3], f32x4 (&acc3)[2][T16]) {
   f32x4 accA[2][16], accB[2][16];
   const SrcXch<0, kPosCh> s_pe{xch_lane, q};
   const SrcXch<kPosCh, kDirCh> s_qe{xch_lane, q};
   const SrcTilesW<16> s_a{accA}, s_b{accB};
   const float* const b8 = cst + kConstBias8 + 4 * q;
 
-  const_section_ready();      // mlps.0 reads its bias before its first stage barrier; the encoding exchange is over
   // ---- mlps.0: position encoding (2 k-steps) -> A
   layer_w<0, 16, 2, 0, false, false, false>(c, accA, b8, s_pe, s_pe);
   // ---- mlps.1 .. mlps.4 in pairs A -> B -> A (rolled)
@@ -231,10 +239,7 @@ __device__ __forceinline__ bool x6w_network(Ctx6& c, const float* cst, const flo
     }
     sigma[p] = sum_groups(s) + cst[kConstDensB];
   }
-  if (sigma_only) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next stage's LDS-DMA must land before the LDS is let go of
-    return true;
-  }
+  if (sigma_only) return true;      // (the stage in flight is stage 0 of the next tile: Ctx6::wrap)
 
   // ---- rgb_feature_linear on h8 (no activation behind it, dm_nerf.py:89) -> A; feature tiles 0 .. kKeepTo-1 of h8 stay
   //      behind activated in vector registers, their accumulators take the 8-tile layers' output
@@ -268,7 +273,7 @@ __device__ __forceinline__ bool x6w_network(Ctx6& c, const float* cst, const flo
   c.g = kX6StageInsH;
   layer_w<8, 8, 8, 0, false, false, false>(c, acc2, cst + kConstBias4 + 128 + 4 * q, s_a, s_pe);
   c.g = kX6StageInsO;
-  layer_w<9, T16, 4, 0, true, false, true>(c, acc3, cst + kConstBiasO + 4 * q, SrcTilesW<8>{acc2}, s_pe);
+  layer_w<9, T16, 4, 0, true, false, true>(c, acc3, cst + kConstBiasO + 4 * q, SrcTilesW<8>{acc2}, s_pe, nullptr, more);
   return false;
 }
 
@@ -339,48 +344,53 @@ constexpr int kXchWave = (kPosCh + kDirCh) * kXchRow;  // 2,970 floats per wave
 constexpr int kXchBytes = 4 * kXchWave * 4;            // 47,520 B behind the stage slots and the const section
 static_assert(kX6LdsBytes + kXchBytes <= 160 * 1024, "LDS budget of one CU");
 
-template <int T16>
-__global__ __launch_bounds__(256, 1) void field_fwd_x6w_kernel(const FieldArgs a) {
-  __shared__ __attribute__((aligned(16))) char lds[kX6LdsBytes + kXchBytes];
-  float* const cst = reinterpret_cast<float*>(lds + kX6Slots * kX6StageBytes);
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, n = lane & 15, q = lane >> 4;
-  const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const char* const blob = static_cast<const char*>(a.blob);
-  Ctx6 c{blob + kConstFloats * 4, lds, nullptr, 0, x6_total_stages(ins_tiles(a.ins_ch - 1)), wave_s, lane};
-
-  // const section + stage 0 start streaming while the encodings are computed
-  for (int k = wave_s; k < kConstChunks; k += 4)
-    glds16(blob + k * 1024 + lane * 16, lds + kX6Slots * kX6StageBytes + k * 1024);
-  x6_load_stage(c, 0);
-
-  // ---- encodings: computed by the two lanes of a point (lane = point + 32 * half: three coordinates each,
-  //      encodings_to_exchange) and left in LDS for the lanes that need them as k-slots: lane (n, q) of point tile p
-  //      takes channels 32 e + 8 q + j of point 16 p + n, where the layers consume them (SrcXch: 80 reads per pass; held
-  //      in registers they cost 48 for most of the kernel).  Rows of 33 floats keep the 32 points of a channel on 32 banks.
-  float* const xch = reinterpret_cast<float*>(lds + kX6LdsBytes) + wave_s * kXchWave;
-  {
-    const int pt = lane & 31, h = lane >> 5;
-    const long m = ((long)blockIdx.x * 4 + wave_s) * 32 + pt;
-    encodings_to_exchange(a, m < a.M ? m : a.M - 1, h, xch + pt);
-    __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): written before this wave's first read (same wave: in order anyway)
-  }
-  const float* const xch_lane = xch + 8 * q * kXchRow + n;
-
-  float sigma[2], rgb[2][3];
-  f32x4 acc3[2][T16];
-  const int C = 4 + a.ins_ch;
-  float* const stage = reinterpret_cast<float*>(lds);                 // the stage buffers, once the network is through
-  const long first = (long)blockIdx.x * 128;
-  const int n_out = (int)(a.M - first < 128 ? a.M - first : 128) * C;
-  if (x6w_network<T16>(c, cst, xch_lane, q, a.sigma_only != 0, sigma, rgb, acc3)) {
-    // density only: raw = [0, 0, 0, sigma, 0 ...] (a branch of its own that ends the kernel: field_fwd_x6.hip)
-    __syncthreads();
+// The point tiles of one workgroup (tile = 128 points; tiles blockIdx.x, + gridDim.x, ...: the launch has one workgroup per
+// CU, which is what the LDS lets a CU hold).  SIGMA: the density-only pass, a loop of its own (field_fwd_x6.hip).
+// The weight stream wraps from a tile's last stage to stage 0 of the next tile, so that only the first tile of a workgroup
+// waits for the const section and for its first stage, and the dispatch of a workgroup is paid once per CU.
+template <int T16, bool SIGMA>
+__device__ __forceinline__ void x6w_tiles(Ctx6& c, char* lds, const float* cst) {
+  float* const rows = reinterpret_cast<float*>(lds + kX6LdsBytes);    // the exchange area; a tile's raw rows once it is through
+  int tile = blockIdx.x;
+  for (;;) {
+    // What a tile needs of the launch's arguments and of the lane's identity is this iteration's: re-read from the kernel
+    // argument segment, re-derived from an opaque lane id.  (Left loop-invariant, ~40 scalar and ~80 vector registers of
+    // hoisted addresses and arguments live across the whole network, which has none to spare: 336 B of scratch.)
+    typedef const __attribute__((address_space(4))) FieldArgs* ArgPtr;
+    ArgPtr ap = (ArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ap), "+s"(c.stream), "+s"(c.wave_s), "+s"(c.par));
+    const FieldArgs a{ap->rays_o, ap->rays_d, ap->z, ap->z_stride, ap->emb, nullptr, ap->raw, nullptr, ap->M, ap->S, ap->ins_ch,
+                      nullptr, 0};
+    const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));     // (no register carries it over)
+    const int tid = c.wave_s * 64 + lane, n = lane & 15, q = lane >> 4;
+    c.lane = lane;
+    // ---- encodings: computed by the two lanes of a point (lane = point + 32 * half: three coordinates each,
+    //      encodings_to_exchange) and left in LDS for the lanes that need them as k-slots: lane (n, q) of point tile p
+    //      takes channels 32 e + 8 q + j of point 16 p + n, where the layers consume them (SrcXch: 80 reads per pass; held
+    //      in registers they cost 48 for most of the kernel).  Rows of 33 floats keep the 32 points of a channel on 32 banks.
+    float* const xch = rows + c.wave_s * kXchWave;
+    const float* const xch_lane = xch + 8 * q * kXchRow + n;
+    const int C = 4 + a.ins_ch;
+    const int n_tiles = (int)((a.M + 127) / 128);
+    const bool more = tile + (int)gridDim.x < n_tiles;
+    {
+      const int pt = lane & 31, h = lane >> 5;
+      const long m = ((long)tile * 4 + c.wave_s) * 32 + pt;
+      encodings_to_exchange(a, m < a.M ? m : a.M - 1, h, xch + pt);
+      __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): written before this wave's first read (same wave: in order anyway)
+    }
+    float sigma[2], rgb[2][3];
+    f32x4 acc3[2][T16];
+    c.g = 0;
+    x6w_network<T16>(c, cst, xch_lane, q, SIGMA, more, sigma, rgb, acc3);
+    // ---- raw = cat([rgb, density, ins]) (dm_nerf.py:105): gathered in LDS, stored as whole lines (field_fwd_x6.hip).  In
+    //      the exchange area: every wave read its last encoding at least thirteen stage barriers ago (the density-only pass:
+    //      sixteen), and the stage slots already receive the next tile's stage 0.
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      float* const row = stage + (wave_s * 32 + 16 * p + n) * C;
+      float* const row = rows + (c.wave_s * 32 + 16 * p + n) * C;
       if (q == 0) {
-        row[0] = 0.f; row[1] = 0.f; row[2] = 0.f;
+        row[0] = SIGMA ? 0.f : rgb[p][0]; row[1] = SIGMA ? 0.f : rgb[p][1]; row[2] = SIGMA ? 0.f : rgb[p][2];
         row[3] = sigma[p];
       }
 #pragma unroll
@@ -388,40 +398,56 @@ __global__ __launch_bounds__(256, 1) void field_fwd_x6w_kernel(const FieldArgs a
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int ch = 16 * t + 4 * q + r;
-          if (ch < a.ins_ch) row[4 + ch] = 0.f;
+          if (ch < a.ins_ch) row[4 + ch] = SIGMA ? 0.f : acc3[p][t][r];     // density only: raw = [0, 0, 0, sigma, 0 ...]
         }
     }
     __syncthreads();
-    store_rows_coalesced_w(stage, a.raw + first * C, n_out, tid);
-    return;
+    const long first = (long)tile * 128;
+    store_rows_coalesced_w(rows, a.raw + first * C, (int)(a.M - first < 128 ? a.M - first : 128) * C, tid);
+    if (!more) break;
+    __syncthreads();                              // the rows are read; the next tile's encodings overwrite them
+    c.par = (c.par + c.G) % kX6Slots;
+    tile += (int)gridDim.x;
   }
-  // ---- raw = cat([rgb, density, ins]) (dm_nerf.py:105): gathered in LDS, stored as whole lines (field_fwd_x6.hip)
-  __syncthreads();                                   // every wave is done with the last weight stage (no DMA in flight)
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    float* const row = stage + (wave_s * 32 + 16 * p + n) * C;
-    if (q == 0) {
-      row[0] = rgb[p][0]; row[1] = rgb[p][1]; row[2] = rgb[p][2];
-      row[3] = sigma[p];
-    }
-#pragma unroll
-    for (int t = 0; t < T16; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ch = 16 * t + 4 * q + r;
-        if (ch < a.ins_ch) row[4 + ch] = acc3[p][t][r];
-      }
-  }
-  __syncthreads();
-  store_rows_coalesced_w(stage, a.raw + first * C, n_out, tid);
+}
+
+template <int T16>
+__global__ __launch_bounds__(256, 1) void field_fwd_x6w_kernel(const FieldArgs a) {
+  __shared__ __attribute__((aligned(16))) char lds[kX6LdsBytes + kXchBytes];
+  float* const cst = reinterpret_cast<float*>(lds + kX6Slots * kX6StageBytes);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const char* const blob = static_cast<const char*>(a.blob);
+  // the density-only pass ends behind the trunk: its stream wraps there
+  Ctx6 c{blob + kConstFloats * 4, lds, nullptr, 0, a.sigma_only ? kX6StageRgbF : x6_total_stages(ins_tiles(a.ins_ch - 1)),
+         wave_s, lane, 0, true};
+
+  for (int k = wave_s; k < kConstChunks; k += 4)
+    glds16(blob + k * 1024 + lane * 16, lds + kX6Slots * kX6StageBytes + k * 1024);
+  x6_load_stage(c, 0);
+  const_section_ready();      // mlps.0 reads its bias before its first stage barrier (once per workgroup)
+  if (a.sigma_only) x6w_tiles<T16, true>(c, lds, cst);
+  else x6w_tiles<T16, false>(c, lds, cst);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // a density-only tile's last stage prefetches past its end: landed
+                                                        // before the LDS is let go of
+}
+
+// one workgroup per CU (the LDS holds one): the tiles are dealt round robin
+int x6w_workgroups(long tiles) {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    return n;
+  }();
+  return tiles < cus ? (int)tiles : cus;
 }
 
 int launch_x6w(const FieldArgs& a, int ins_num, hipStream_t st) {
   if (ins_num < 0 || ins_tiles(ins_num) > kMaxInsTiles) return DMN_ERR_UNSUPPORTED;
   if (a.M <= 0) return DMN_OK;
-  const long blocks = (a.M + 127) / 128;
-  if (blocks > 0x7fffffffL) return DMN_ERR_UNSUPPORTED;
-  const dim3 grid((unsigned)blocks), block(256);
+  const dim3 grid((unsigned)x6w_workgroups((a.M + 127) / 128)), block(256);
   switch (x6w_ins_tiles(ins_num)) {
     case 1: hipLaunchKernelGGL(field_fwd_x6w_kernel<1>, grid, block, 0, st, a); break;
     case 2: hipLaunchKernelGGL(field_fwd_x6w_kernel<2>, grid, block, 0, st, a); break;

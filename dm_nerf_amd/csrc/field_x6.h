@@ -76,12 +76,17 @@ struct Ctx6 {
   const char* buf;      // this lane's read base inside the current stage
   int g, G;             // next stage to begin, number of stages
   int wave_s, lane;
+  // a workgroup that walks several point tiles (field_fwd_x6w.hip): the stream wraps -- the stage behind the last one
+  // is stage 0 of the next tile -- and `par` is the number of stages of the tiles before, modulo the slot count
+  int par = 0;
+  bool wrap = false;
 };
+__device__ __forceinline__ int x6_slot(const Ctx6& c, int g) { return x6_slot(g + c.par); }
 
 // each wave DMA-copies 12 of a stage's 48 chunks
 __device__ __forceinline__ void x6_load_stage(const Ctx6& c, int g) {
   const char* src = c.stream + (long)g * kX6StageBytes + (c.wave_s * kX6PiecesPerWave) * 1024;
-  char* dst = c.lds + x6_slot(g) * kX6StageBytes + (c.wave_s * kX6PiecesPerWave) * 1024;
+  char* dst = c.lds + x6_slot(c, g) * kX6StageBytes + (c.wave_s * kX6PiecesPerWave) * 1024;
 #pragma unroll
   for (int q = 0; q < kX6PiecesPerWave; ++q) glds16_u(src + q * 1024, (unsigned)c.lane * 16u, dst + q * 1024);
 }
@@ -100,7 +105,7 @@ __device__ __forceinline__ void x6_stage_begin(Ctx6& c) {
 #if DMN_X6_ABL != 3
   __syncthreads();
 #endif
-  c.buf = c.lds + x6_slot(c.g) * kX6StageBytes + c.lane * 16;
+  c.buf = c.lds + x6_slot(c, c.g) * kX6StageBytes + c.lane * 16;
   ++c.g;
 }
 
@@ -114,10 +119,10 @@ __device__ __forceinline__ void x6_load_piece(const Ctx6& c) {
   return;
 #endif
   const int gt = c.g + kX6Slots - 2;
-  const int g = gt < c.G ? gt : c.G - 1;
+  const int g = gt < c.G ? gt : (c.wrap ? gt - c.G : c.G - 1);
   const char* src = c.stream + ((unsigned)g * (unsigned)kX6StageBytes + (unsigned)(c.wave_s * kX6PiecesPerWave * 1024));
   const unsigned dst = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)c.lds +
-                       (unsigned)(x6_slot(gt) * kX6StageBytes + c.wave_s * kX6PiecesPerWave * 1024);
+                       (unsigned)(x6_slot(c, gt) * kX6StageBytes + c.wave_s * kX6PiecesPerWave * 1024);
   glds16_at<Q * 1024, NT>(src, (unsigned)c.lane * 16u, dst);
 }
 

@@ -386,24 +386,43 @@ __device__ __forceinline__ void x6w_tiles(Ctx6& c, char* lds, const float* cst) 
     // ---- raw = cat([rgb, density, ins]) (dm_nerf.py:105): gathered in LDS, stored as whole lines (field_fwd_x6.hip).  In
     //      the exchange area: every wave read its last encoding at least thirteen stage barriers ago (the density-only pass:
     //      sixteen), and the stage slots already receive the next tile's stage 0.
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      float* const row = rows + (c.wave_s * 32 + 16 * p + n) * C;
-      if (q == 0) {
-        row[0] = SIGMA ? 0.f : rgb[p][0]; row[1] = SIGMA ? 0.f : rgb[p][1]; row[2] = SIGMA ? 0.f : rgb[p][2];
-        row[3] = sigma[p];
-      }
-#pragma unroll
-      for (int t = 0; t < T16; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int ch = 16 * t + 4 * q + r;
-          if (ch < a.ins_ch) row[4 + ch] = SIGMA ? 0.f : acc3[p][t][r];     // density only: raw = [0, 0, 0, sigma, 0 ...]
-        }
-    }
-    __syncthreads();
+    //      Rows wider than 92 floats (128 of them no longer fit the exchange's 47.5 KB) leave in two halves of 64.
+    const bool halves = 128 * C * 4 > kXchBytes;
     const long first = (long)tile * 128;
-    store_rows_coalesced_w(rows, a.raw + first * C, (int)(a.M - first < 128 ? a.M - first : 128) * C, tid);
+    auto write_rows = [&](int slot) {            // this wave's 32 rows into row slots 32 slot .. 32 slot + 31 of the area
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        float* const row = rows + (slot * 32 + 16 * p + n) * C;
+        if (q == 0) {
+          row[0] = SIGMA ? 0.f : rgb[p][0]; row[1] = SIGMA ? 0.f : rgb[p][1]; row[2] = SIGMA ? 0.f : rgb[p][2];
+          row[3] = sigma[p];
+        }
+#pragma unroll
+        for (int t = 0; t < T16; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int ch = 16 * t + 4 * q + r;
+            if (ch < a.ins_ch) row[4 + ch] = SIGMA ? 0.f : acc3[p][t][r];       // density only: raw = [0, 0, 0, sigma, 0 ...]
+          }
+      }
+    };
+    auto store_rows = [&](long r0, int cap) {    // rows r0 .. of the launch (at most cap of them) out of the area
+      const long left = a.M - r0;
+      store_rows_coalesced_w(rows, a.raw + r0 * C, (int)(left < 0 ? 0 : (left < cap ? left : cap)) * C, tid);
+    };
+    if (!halves) {
+      write_rows(c.wave_s);
+      __syncthreads();
+      store_rows(first, 128);
+    } else {
+      if (c.wave_s < 2) write_rows(c.wave_s);
+      __syncthreads();
+      store_rows(first, 64);
+      __syncthreads();                            // the first half is read: the second overwrites it
+      if (c.wave_s >= 2) write_rows(c.wave_s - 2);
+      __syncthreads();
+      store_rows(first + 64, 64);
+    }
     if (!more) break;
     __syncthreads();                              // the rows are read; the next tile's encodings overwrite them
     c.par = (c.par + c.G) % kX6Slots;
@@ -452,8 +471,9 @@ int launch_x6w(const FieldArgs& a, int ins_num, hipStream_t st) {
     case 1: hipLaunchKernelGGL(field_fwd_x6w_kernel<1>, grid, block, 0, st, a); break;
     case 2: hipLaunchKernelGGL(field_fwd_x6w_kernel<2>, grid, block, 0, st, a); break;
     case 4: hipLaunchKernelGGL(field_fwd_x6w_kernel<4>, grid, block, 0, st, a); break;
-    default: return DMN_ERR_UNSUPPORTED;      // more than 64 channels (6 or 8 instance tiles): the acc3 tiles no longer fit
-                                               // beside the two accumulator sets (7 KB of scratch): field_fwd_x6_kernel serves them
+    case 6: hipLaunchKernelGGL(field_fwd_x6w_kernel<6>, grid, block, 0, st, a); break;
+    case 8: hipLaunchKernelGGL(field_fwd_x6w_kernel<8>, grid, block, 0, st, a); break;
+    default: return DMN_ERR_UNSUPPORTED;
   }
   return hipGetLastError() == hipSuccess ? DMN_OK : DMN_ERR_LAUNCH;
 }

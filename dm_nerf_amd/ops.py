@@ -19,7 +19,7 @@ MAX_INS_CHANNELS = 128
 # "bf16x6" runs inference on the 16x16x32 kernel where that exists (uses_x6w) -- same arithmetic, other summation order
 PRECISIONS = {"fp32": 0, "fp16x3": 1, "bf16x3": 2, "bf16x6": 3, "bf16x6_32": 3}
 X6_PRECISIONS = ("bf16x6", "bf16x6_32")
-X6W_MAX_CHANNELS = 64     # ins_num + 1 up to which the 16x16x32 inference kernel is used (csrc/field_fwd_x6w.hip)
+X6W_MAX_CHANNELS = 128    # ins_num + 1 up to which the 16x16x32 inference kernel is used (csrc/field_fwd_x6w.hip): all of them
 
 
 def uses_x6w(ins_num: int, precision: str = "bf16x6") -> bool:

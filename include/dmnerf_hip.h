@@ -38,7 +38,7 @@ extern "C" {
 #define DMN_PREC_BF16X6 3  /* 6 x v_mfma_f32_32x32x16_bf16 per product on EXACT hi/mid/lo bf16 splits of both operands:
                               all 24 significand bits of the fp32 operands enter the products (fp32-grade arithmetic) */
 #define DMN_PREC_BF16X6W 4 /* the DMN_PREC_BF16X6 arithmetic on v_mfma_f32_16x16x32_bf16 (csrc/field_fwd_x6w.hip): inference
-                            * entry points only (dmn_render_rays), ins_num + 1 <= 64, "x6w" blob; another summation order,
+                            * entry points only (dmn_render_rays), "x6w" blob; another summation order,
                             * so results differ from DMN_PREC_BF16X6 by fp32 rounding */
 /* bits of the sticky status word the split-precision kernels OR into */
 #define DMN_STATUS_FP16_RANGE 1  /* an activation left the fp16 range: re-run with another precision */
@@ -127,8 +127,8 @@ int dmn_field_pack_index_x6(int ins_num, int32_t* index_out);
 int dmn_field_pack_x6(const float* params, const int32_t* index, int ins_num, void* blob, void* stream);
 /* The same arithmetic on v_mfma_f32_16x16x32_bf16 (csrc/field_fwd_x6w.hip; inference): same blob size and gather
  * kernel (dmn_field_blob_x6_bytes, dmn_field_pack_index_x6_len, dmn_field_pack_x6), its own element order
- * (dmn_field_pack_index_x6w); replaces the same reference lines as dmn_field_fwd_rays_x6 / _embedded_x6.  Serves
- * ins_num + 1 <= 64 (DMN_ERR_UNSUPPORTED beyond: use the x6 entry points). */
+ * (dmn_field_pack_index_x6w); replaces the same reference lines as dmn_field_fwd_rays_x6 / _embedded_x6.  Every head
+ * width the x6 entry points serve (ins_num + 1 <= 128). */
 int dmn_field_pack_index_x6w(int ins_num, int32_t* index_out);
 int dmn_field_fwd_rays_x6w(const float* rays_o, const float* rays_d, const float* z, long z_ray_stride, long n_rays,
                            int n_samples, const void* blob, int ins_num, int sigma_only, float* raw, void* stream);

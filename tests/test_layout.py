@@ -592,7 +592,7 @@ def simulate_x6w(idx, flat, emb, ins_num):
     return np.concatenate([out[0].T, out[1].T], 0)                 # [32 points][channels]
 
 
-@pytest.mark.parametrize("ins_num,seed", [(13, 0), (40, 5), (93, 3)])
+@pytest.mark.parametrize("ins_num,seed", [(13, 0), (40, 5), (93, 3), (127, 4)])
 def test_x6w_blob_consumed_in_kernel_order_equals_the_field_to_fp32_rounding(ins_num, seed):
     lib = dm_nerf_amd.load_library()
     n = lib.dmn_field_pack_index_x6_len(ins_num)               # same size as the x6 blob: same bytes, other order

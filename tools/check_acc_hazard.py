@@ -8,7 +8,7 @@
    between 8).  Reads the compiler generated are its own business and are not held against these numbers.  Rolled loops are walked twice (every backward branch
    is followed once), so a read at the top of a loop body is also held against the MFMAs at its bottom.
 2. --lean KERNEL_SUBSTRING (repeatable): kernels whose name contains it must have no scratch
-   (.amdhsa_private_segment_fixed_size 0) and no v_writelane / v_readlane SGPR parking (the 580-writelane regression of
+   (.amdhsa_private_segment_fixed_size 0) and at most 32 v_writelane / v_readlane (SGPR parking: the 580-writelane regression of
    experiments/README.md, "Compiler notes").
 
     hipcc ... -S --cuda-device-only -o x.s field_fwd_x6.hip && python tools/check_acc_hazard.py x.s --lean x6_kernel"""
@@ -16,6 +16,7 @@ import re
 import sys
 
 KERNEL_TAGS = ("x3_kernel", "x6_kernel", "x6w_kernel")
+MAX_LANE_OPS = 32     # a handful of scalars parked around a tile's epilogue is not the regression (580 per pass)
 
 
 def min_wait_states(mfma: str) -> int:
@@ -122,7 +123,7 @@ def main(argv):
                   f"scratch {scratch.get(name, '?')} B, v_writelane/v_readlane {lanes}")
             worst_all = worst if worst_all is None else min(worst_all, worst)
         if any(t in name for t in lean):
-            if scratch.get(name) != 0 or lanes != 0:
+            if scratch.get(name) != 0 or lanes > MAX_LANE_OPS:
                 print(f"NOT LEAN: {name[:100]}: scratch {scratch.get(name)} B, v_writelane/v_readlane {lanes}")
                 ok = False
     return 0 if ok and worst_all is not None and worst_all >= 0 else 1

@@ -1,5 +1,6 @@
 """Timing probe (GPU box): the field kernel of every arithmetic on the bench's launch shapes (65536-ray chunks, S = 64 and
 192), HIP events around each launch, interleaved rounds on one device.  Prints ms per launch and algorithmic TFLOP/s."""
+import os
 import sys
 import time
 
@@ -12,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dm_nerf_amd as dm
 from dm_nerf_amd import ops, synthetic
 
-INS = 13
+INS = int(os.environ.get("PROBE_INS", "13"))
 FLOP_PER_POINT = 2 * 693504
 
 

@@ -1686,6 +1686,37 @@ def test_render_call_is_bit_identical_from_launch_to_launch(precision):
     assert all(np.isfinite(H(v)).all() for v in first.values())
 
 
+@pytest.mark.parametrize("ins_num", [13, 40, 93, 127])
+def test_tile_loop_gives_every_tile_the_bits_it_gets_alone(ins_num):
+    """field_fwd_x6w_kernel runs one workgroup per CU that walks the launch's 128-point tiles, the weight stream wrapping
+    from a tile's last stage into the next tile's first (slot parity carried over tiles when the stage count is odd: 6 and
+    8 instance tiles).  A launch in which every workgroup walks 3 - 4 tiles (ragged tail included) against the same rays
+    in launches of fewer tiles than the device has CUs (one tile per workgroup, nothing wraps): bit for bit the same
+    rows, full and density-only."""
+    rng = np.random.default_rng(ins_num)
+    model = dm.DM_NeRF(8, 256, 63, 27, [4], ins_num).to(DEV)
+    model.load_state_dict(oracle.make_params(ins_num, 5))
+    blob = model.blob("bf16x6")
+    n, s = 601, 191                                                # 114 791 points = 897 tiles, the last one ragged
+    o = G(rng.uniform(-1, 1, size=(n, 3)).astype(np.float32))
+    d = G(rng.standard_normal((n, 3)).astype(np.float32))
+    z = G(np.sort(rng.uniform(cases.NEAR, cases.FAR, size=(n, s)).astype(np.float32), -1))
+    cus = torch.cuda.get_device_properties(DEV).multi_processor_count
+    step = max(1, (min(cus, 200) * 128) // s - 1)                  # rays per small launch: fewer tiles than CUs
+    assert (n * s + 127) // 128 > 3 * cus or cus > 256
+    for sigma_only in (False, True):
+        whole = ops.field_rays(o, d, z, blob, ins_num, "bf16x6", sigma_only=sigma_only)
+        for lo in range(0, n, step):
+            part = ops.field_rays(o[lo:lo + step], d[lo:lo + step], z[lo:lo + step], blob, ins_num, "bf16x6", sigma_only=sigma_only)
+            assert torch.equal(part, whole[lo:lo + step]), (sigma_only, lo)
+        if sigma_only:
+            assert torch.equal(whole[..., 3], full[..., 3])
+            assert float(whole[..., :3].abs().max()) == 0.0 and float(whole[..., 4:].abs().max()) == 0.0
+        else:
+            full = whole
+            assert bool(torch.isfinite(full).all())
+
+
 # ---- the one-call C entry for a chunk ----------------------------------------------------------------------
 @pytest.mark.parametrize("precision,stochastic", [("fp32", False), ("bf16x3", True), ("bf16x6", True), ("bf16x6", False)])
 def test_render_rays_entry_point_equals_the_chained_calls(precision, stochastic):
